@@ -1,0 +1,201 @@
+/*
+ * shader_ray_hip.h -- C ABI of the MI355X (gfx950) per-pixel tracer.
+ *
+ * This is the drop-in boundary for shader-ray's hot path.  In the reference
+ * the path sits behind three OpenGL call groups; each entry point below
+ * names the reference interface it replaces (file:line into the upstream
+ * repository):
+ *
+ *   shray_scene_create      <- texture upload in load_scene_data, ray.cpp:470-497
+ *                              (payload = scene_shader_data, world.h:68-93)
+ *   shray_scene_set_environment
+ *                           <- background texture upload, ray.cpp:499-510
+ *                              (payload = float2Dimage, ray.cpp:330-343)
+ *   shray_render / shray_render_device
+ *                           <- uniform block + glDrawArrays in DrawFrame,
+ *                              ray.cpp:648-707, and the glReadPixels readback
+ *                              in screenshot, ray.cpp:760
+ *   shray_scene_destroy     <- (GL objects are never freed upstream)
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  All matrices are
+ * column-major float[16] exactly as the reference hands them to
+ * glUniformMatrix4fv(..., GL_FALSE, ...) (vectormath.h:258-272).
+ *
+ * Ownership: shray_scene_create / shray_scene_set_environment copy what they
+ * need to the device; the caller keeps its host arrays.  Output buffers are
+ * caller-owned.
+ * Errors: every function returns SHRAY_OK (0) or a negative code; a
+ * human-readable message for the calling thread's last failure is available
+ * from shray_last_error().  Nothing exits or throws across this boundary.
+ * Threading: calls on one handle are not re-entrant; different handles may be
+ * driven from different threads / processes (one handle per GPU).
+ */
+#ifndef SHADER_RAY_HIP_H
+#define SHADER_RAY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHRAY_ABI_VERSION 1
+
+enum {
+    SHRAY_OK = 0,
+    SHRAY_ERR_INVALID_ARGUMENT = -1,
+    SHRAY_ERR_NO_DEVICE = -2,       /* HIP runtime reports no usable gfx950 device */
+    SHRAY_ERR_DEVICE = -3,          /* a HIP call failed; see shray_last_error() */
+    SHRAY_ERR_OUT_OF_MEMORY = -4,
+    SHRAY_ERR_INDEX_RANGE = -5,     /* an index does not survive float32 storage (>= 2^24) */
+    SHRAY_ERR_BAD_TREE = -6,        /* hit/miss tables are not a well-formed threaded tree */
+    SHRAY_ERR_NO_ENVIRONMENT = -7   /* render called before shray_scene_set_environment */
+};
+
+/*
+ * Flattened scene: the arrays get_shader_data() produces (world.cpp:298-347),
+ * taken verbatim.  Every array is float32, padded to data_texture_width *
+ * rows texels like the textures they were uploaded as (ray.cpp:470-497).
+ *
+ *   vertex_positions / vertex_normals : 3 floats per vertex, 3 vertices per
+ *       triangle in post-build triangle order (world.cpp:304-317)
+ *   group_boxmin / group_boxmax       : 3 floats per node (world.cpp:183-188)
+ *   group_hitmiss                     : 8 tables of (hit, miss) float pairs;
+ *       table c starts at texel c * data_texture_width * group_data_rows
+ *       (world.cpp:343-346, raytracer.es.fs:392); >= 16777215 terminates
+ *   group_objects                     : (start, count) per node, 0,0 for
+ *       branches (world.cpp:201-208)
+ *
+ * vertex_colors, group_directions and group_children are uploaded by the
+ * reference but never read by the shader; they may be NULL here.
+ */
+typedef struct shray_scene_desc {
+    uint32_t struct_size;          /* sizeof(shray_scene_desc), for ABI checking */
+    uint32_t data_texture_width;   /* ray.cpp:326, 2048 upstream */
+
+    uint32_t vertex_count;         /* 3 * triangle count */
+    uint32_t vertex_data_rows;
+    const float *vertex_positions;
+    const float *vertex_normals;
+    const float *vertex_colors;    /* optional, unused */
+
+    int32_t group_count;
+    int32_t group_data_rows;
+    int32_t tree_root;
+    const float *group_boxmin;
+    const float *group_boxmax;
+    const float *group_directions; /* optional, unused */
+    const float *group_children;   /* optional, unused */
+    const float *group_hitmiss;
+    const float *group_objects;
+} shray_scene_desc;
+
+/*
+ * Per-frame parameter block: the uniforms DrawFrame sets (ray.cpp:648-704)
+ * plus the shader's compile-time constants, which are exposed here with the
+ * reference values as defaults (see shray_frame_params_init).
+ */
+typedef struct shray_frame_params {
+    uint32_t struct_size;            /* sizeof(shray_frame_params) */
+
+    int32_t which;                   /* ray.cpp:648; 0 = normal rendering */
+
+    float camera_matrix[16];         /* ray.cpp:654 */
+    float camera_normal_matrix[16];  /* ray.cpp:655 */
+    float object_matrix[16];         /* ray.cpp:656 */
+    float object_inverse[16];        /* ray.cpp:657 (unused by the shader) */
+    float object_normal_matrix[16];  /* ray.cpp:658 */
+    float object_normal_inverse[16]; /* ray.cpp:659 */
+
+    float image_plane_width;         /* ray.cpp:672, 2*tanf(fov/2) */
+    float aspect;                    /* ray.cpp:673, height / width */
+    float right[3];                  /* ray.cpp:677-679 */
+    float up[3];                     /* ray.cpp:681-683 */
+    float light_dir[3];              /* ray.cpp:695 */
+    float specular_color[3];         /* ray.cpp:699 */
+    float diffuse_color[3];          /* ray.cpp:700-704; 0 for metals */
+
+    /* shader constants (raytracer.es.fs:550,381,382,445,525) */
+    int32_t bounce_count;            /* 3 */
+    int32_t max_bvh_iterations;      /* 400 */
+    int32_t max_leaf_tests;          /* 10 */
+    int32_t cast_shadows;            /* 1 */
+    int32_t tonemap;                 /* 1 (filmic) */
+    int32_t normals_fp16;            /* 1: normals were uploaded as GL_RGB16F, ray.cpp:474 */
+} shray_frame_params;
+
+/* Interleaved-tile ownership for splitting one frame over several GPUs.
+ * The frame is cut into tile_w x tile_h tiles, numbered row-major; this
+ * handle renders the tiles with (tile_index % tile_stride) == tile_phase and
+ * packs them densely, in increasing tile index, into the output buffer
+ * (each tile stored row-major, tile_w*tile_h RGBA texels, edge tiles padded).
+ * {0,0,1,0} or NULL = whole frame, plain row-major output. */
+typedef struct shray_tile_set {
+    int32_t tile_w;
+    int32_t tile_h;
+    int32_t tile_stride;
+    int32_t tile_phase;
+} shray_tile_set;
+
+/* Work counters of one render, summed over all pixels and samples.  They feed
+ * the algorithmic-bytes formula of the roofline report. */
+typedef struct shray_counters {
+    uint64_t node_visits;      /* group_intersect loop iterations (raytracer.es.fs:395) */
+    uint64_t leaf_visits;      /* leaves whose (start,count) was fetched (:263-267) */
+    uint64_t triangle_tests;   /* triangle_intersect calls (:416) */
+    uint64_t shaded_hits;      /* shade() calls with a valid hit (:505) */
+    uint64_t env_lookups;      /* sample_environment calls (:580) */
+    uint64_t traversals;       /* group_intersect calls, closest-hit + shadow */
+    uint64_t bad_hits;         /* samples that returned the iteration-cap marker (:436-438) */
+    uint64_t samples;          /* width * height * spp */
+} shray_counters;
+
+typedef struct shray_scene shray_scene;
+
+/* Library / device ------------------------------------------------------- */
+int shray_abi_version(void);
+const char *shray_last_error(void);
+int shray_device_count(int *count);
+/* Selects the HIP device used by scenes created afterwards on this thread. */
+int shray_set_device(int device_index);
+
+/* Parameters ------------------------------------------------------------- */
+/* Fills struct_size, identity matrices and the shader-constant defaults. */
+void shray_frame_params_init(shray_frame_params *params);
+
+/* Scene ------------------------------------------------------------------ */
+int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene);
+int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height);
+int shray_scene_destroy(shray_scene *scene);
+
+/* Kernel selection: 0 = default (fastest parity-exact kernel),
+ * 1 = literal threaded hit/miss-table traversal over the reference arrays. */
+int shray_scene_set_kernel(shray_scene *scene, int kernel_id);
+
+/* Render ----------------------------------------------------------------- */
+/* Output is RGBA float32, row 0 = bottom row of the image (GL origin,
+ * raytracer.vs:56), alpha = 1 (raytracer.es.fs:676). */
+int shray_render(shray_scene *scene, const shray_frame_params *params,
+                 int width, int height, int spp, float *rgba_out_host);
+
+/* Asynchronous form: d_rgba_out is device memory on the scene's device,
+ * hip_stream a hipStream_t (NULL = default stream).  tiles may be NULL.
+ * Required size in bytes: shray_tile_buffer_bytes(). */
+int shray_render_device(shray_scene *scene, const shray_frame_params *params,
+                        int width, int height, int spp,
+                        const shray_tile_set *tiles,
+                        void *d_rgba_out, void *hip_stream);
+
+int64_t shray_tile_buffer_bytes(int width, int height, const shray_tile_set *tiles);
+
+/* Same render with per-ray work counters accumulated (slower; used for the
+ * roofline's algorithmic-byte count and for parity of the traversal itself). */
+int shray_render_counters(shray_scene *scene, const shray_frame_params *params,
+                          int width, int height, int spp,
+                          float *rgba_out_host /* may be NULL */,
+                          shray_counters *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHADER_RAY_HIP_H */

@@ -1,0 +1,68 @@
+/*
+ * shader_ray_host.h -- C view of the host-side loader / BVH / flattener.
+ *
+ * The host layer itself is C++ and keeps the reference's API (world.h,
+ * bvh.h, group.h, triangle-set.h, trisrc-support.h, obj-support.h under
+ * shader-ray_amd/host/).  These wrappers exist so that non-C++ callers (the
+ * Python test and bench drivers, via ctypes) can reach it; each names the
+ * C++ entry point -- and through it the reference interface -- it forwards to.
+ */
+#ifndef SHADER_RAY_HOST_H
+#define SHADER_RAY_HOST_H
+
+#include "shader_ray_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shray_host_world shray_host_world;
+
+/* Interactive state of the reference's shell (globals at ray.cpp:38-74) with
+ * the start-up values of ray.cpp:1077-1088. */
+typedef struct shray_host_view {
+    float fov;                 /* radians; 40 degrees */
+    float zoom;                /* scene_extent / 2 / sinf(fov / 2) */
+    float object_rotation[4];  /* angle, axis */
+    float object_position[3];
+    float light_rotation[4];   /* -20 degrees about (.707, -.707, 0) */
+    int32_t which;
+    int32_t which_material;    /* index into the materials table, ray.cpp:54-65 */
+    int32_t which_diffuse_color; /* ray.cpp:68-73 */
+} shray_host_view;
+
+typedef struct shray_host_world_info {
+    int32_t triangle_count;
+    int32_t independent_vertex_count;
+    float scene_center[3];
+    float scene_extent;
+    int32_t node_count;
+    int32_t leaf_count;
+    int32_t max_level;
+    int32_t large_leaves;
+    double parse_seconds;
+    double build_seconds;
+} shray_host_world_info;
+
+/* load_world() (world.h:64): parse .trisrc / .obj, centre + extent, make_bvh.
+ * Returns 0 or -1 (message on stderr, like the reference). */
+int shray_host_load_world(const char *filename, shray_host_world **out_world);
+void shray_host_free_world(shray_host_world *world);
+int shray_host_get_world_info(const shray_host_world *world, shray_host_world_info *info);
+
+/* get_shader_data() (world.h:95).  The arrays named by *desc stay owned by
+ * `world` and valid until it is freed or flattened again. */
+int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width, shray_scene_desc *desc);
+
+/* Start-up view (ray.cpp:1077-1088) and the per-frame block (ray.cpp:648-704). */
+int shray_host_default_view(const shray_host_world *world, shray_host_view *view);
+int shray_host_frame_params(shray_host_world *world, const shray_host_view *view, int width, int height,
+                            shray_frame_params *params);
+
+/* Quiet (1) drops the loaders' progress chatter on stderr; errors still print. */
+void shray_host_set_quiet(int quiet);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

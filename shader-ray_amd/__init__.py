@@ -1,0 +1,7 @@
+"""shader-ray hot path for MI355X: host loaders + BVH (C++), HIP tracer (C ABI).
+
+The directory name carries a hyphen (it is fixed by the project layout), so import it
+through `__graft_entry__.load_package()`, which registers it as `shader_ray_amd`.
+"""
+from . import _native, host, scenes  # noqa: F401
+from .host import World  # noqa: F401

@@ -1,0 +1,156 @@
+"""ctypes mirror of include/shader_ray_hip.h and include/shader_ray_host.h.
+
+Plumbing only: structure layouts, library loading, error translation.  There is no
+CPU fallback -- if a shared library is missing the loaders raise, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(PKG_DIR, "libshray_host.so")
+HIP_LIB = os.path.join(PKG_DIR, "libshray_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("data_texture_width", C.c_uint32),
+        ("vertex_count", C.c_uint32), ("vertex_data_rows", C.c_uint32),
+        ("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_colors", c_float_p),
+        ("group_count", C.c_int32), ("group_data_rows", C.c_int32), ("tree_root", C.c_int32),
+        ("group_boxmin", c_float_p), ("group_boxmax", c_float_p),
+        ("group_directions", c_float_p), ("group_children", c_float_p),
+        ("group_hitmiss", c_float_p), ("group_objects", c_float_p),
+    ]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("which", C.c_int32),
+        ("camera_matrix", C.c_float * 16), ("camera_normal_matrix", C.c_float * 16),
+        ("object_matrix", C.c_float * 16), ("object_inverse", C.c_float * 16),
+        ("object_normal_matrix", C.c_float * 16), ("object_normal_inverse", C.c_float * 16),
+        ("image_plane_width", C.c_float), ("aspect", C.c_float),
+        ("right", C.c_float * 3), ("up", C.c_float * 3), ("light_dir", C.c_float * 3),
+        ("specular_color", C.c_float * 3), ("diffuse_color", C.c_float * 3),
+        ("bounce_count", C.c_int32), ("max_bvh_iterations", C.c_int32), ("max_leaf_tests", C.c_int32),
+        ("cast_shadows", C.c_int32), ("tonemap", C.c_int32), ("normals_fp16", C.c_int32),
+    ]
+
+    def copy(self) -> "FrameParams":
+        other = FrameParams()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(FrameParams))
+        return other
+
+
+class TileSet(C.Structure):
+    _fields_ = [("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tile_stride", C.c_int32), ("tile_phase", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "node_visits", "leaf_visits", "triangle_tests", "shaded_hits", "env_lookups",
+        "traversals", "bad_hits", "samples")]
+
+    def as_dict(self) -> dict:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class HostView(C.Structure):
+    _fields_ = [
+        ("fov", C.c_float), ("zoom", C.c_float), ("object_rotation", C.c_float * 4),
+        ("object_position", C.c_float * 3), ("light_rotation", C.c_float * 4),
+        ("which", C.c_int32), ("which_material", C.c_int32), ("which_diffuse_color", C.c_int32),
+    ]
+
+
+class HostWorldInfo(C.Structure):
+    _fields_ = [
+        ("triangle_count", C.c_int32), ("independent_vertex_count", C.c_int32),
+        ("scene_center", C.c_float * 3), ("scene_extent", C.c_float),
+        ("node_count", C.c_int32), ("leaf_count", C.c_int32), ("max_level", C.c_int32),
+        ("large_leaves", C.c_int32), ("parse_seconds", C.c_double), ("build_seconds", C.c_double),
+    ]
+
+
+# Every symbol include/shader_ray_hip.h declares: (name, restype, argtypes)
+HIP_SYMBOLS = [
+    ("shray_abi_version", C.c_int, []),
+    ("shray_last_error", C.c_char_p, []),
+    ("shray_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("shray_set_device", C.c_int, [C.c_int]),
+    ("shray_frame_params_init", None, [C.POINTER(FrameParams)]),
+    ("shray_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
+    ("shray_scene_set_environment", C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int]),
+    ("shray_scene_destroy", C.c_int, [C.c_void_p]),
+    ("shray_scene_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
+    ("shray_render", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, c_float_p]),
+    ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
+    ("shray_tile_buffer_bytes", C.c_int64, [C.c_int, C.c_int, C.POINTER(TileSet)]),
+    ("shray_render_counters", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
+                                        c_float_p, C.POINTER(Counters)]),
+]
+
+HOST_SYMBOLS = [
+    ("shray_host_load_world", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("shray_host_free_world", None, [C.c_void_p]),
+    ("shray_host_get_world_info", C.c_int, [C.c_void_p, C.POINTER(HostWorldInfo)]),
+    ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
+    ("shray_host_default_view", C.c_int, [C.c_void_p, C.POINTER(HostView)]),
+    ("shray_host_frame_params", C.c_int, [C.c_void_p, C.POINTER(HostView), C.c_int, C.c_int, C.POINTER(FrameParams)]),
+    ("shray_host_set_quiet", None, [C.c_int]),
+]
+
+_host = None
+_hip = None
+
+
+def _bind(lib, table):
+    for name, restype, argtypes in table:
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+def load_host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} is not built; run `python __graft_entry__.py build` (or `make -C shader-ray_amd`)")
+        _host = _bind(C.CDLL(HOST_LIB), HOST_SYMBOLS)
+    return _host
+
+
+def load_hip():
+    """Loads the HIP layer.  torch (when installed) is imported first so that both share
+    one HIP runtime: torch bundles its own libamdhip64 under the same SONAME."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"{HIP_LIB} is not built; run `python __graft_entry__.py build` (or `make -C shader-ray_amd`). "
+                               "There is no CPU fallback for the tracer.")
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _hip = _bind(C.CDLL(HIP_LIB), HIP_SYMBOLS)
+        if _hip.shray_abi_version() != 1:
+            raise RuntimeError("libshray_hip.so ABI version mismatch")
+    return _hip
+
+
+class ShrayError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"shray error {code}: {message}")
+        self.code = code
+
+
+def check(code: int):
+    if code != 0:
+        msg = load_hip().shray_last_error()
+        raise ShrayError(code, msg.decode() if msg else "")

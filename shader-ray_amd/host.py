@@ -1,0 +1,96 @@
+"""Python face of the host layer: load a scene file, build the BVH, flatten it, and
+produce frame parameters -- the same steps the reference's `main` performs before its
+first draw call (reference ray.cpp:954-1092), minus the window."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class World:
+    """A loaded scene (`load_world`, reference world.cpp:46) plus its flattened arrays."""
+
+    def __init__(self, filename: str, quiet: bool = True):
+        lib = N.load_host()
+        lib.shray_host_set_quiet(1 if quiet else 0)
+        handle = C.c_void_p()
+        if lib.shray_host_load_world(filename.encode(), C.byref(handle)) != 0 or not handle:
+            raise RuntimeError(f"load_world failed for {filename!r} (see stderr)")
+        self._lib = lib
+        self._handle = handle
+        self._desc = None
+        info = N.HostWorldInfo()
+        lib.shray_host_get_world_info(handle, C.byref(info))
+        self.info = info
+
+    def close(self):
+        if self._handle:
+            self._lib.shray_host_free_world(self._handle)
+            self._handle = None
+            self._desc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def triangle_count(self) -> int:
+        return self.info.triangle_count
+
+    def flatten(self, data_texture_width: int = 2048) -> N.SceneDesc:
+        """`get_shader_data` (reference world.cpp:298).  The returned descriptor points
+        into memory owned by this World."""
+        desc = N.SceneDesc()
+        if self._lib.shray_host_flatten(self._handle, data_texture_width, C.byref(desc)) != 0:
+            raise RuntimeError("get_shader_data failed")
+        self._desc = desc
+        return desc
+
+    def arrays(self, data_texture_width: int = 2048) -> dict:
+        """The flattened arrays as numpy copies (populated prefix only), keyed like
+        scene_shader_data (reference world.h:68-93)."""
+        d = self._desc if self._desc is not None else self.flatten(data_texture_width)
+        nv, ng = d.vertex_count, d.group_count
+        stride = d.data_texture_width * d.group_data_rows
+
+        def take(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+
+        out = {
+            "vertex_count": nv, "vertex_data_rows": d.vertex_data_rows, "group_count": ng,
+            "group_data_rows": d.group_data_rows, "tree_root": d.tree_root,
+            "vertex_positions": take(d.vertex_positions, 3 * nv), "vertex_normals": take(d.vertex_normals, 3 * nv),
+            "vertex_colors": take(d.vertex_colors, 3 * nv),
+            "group_boxmin": take(d.group_boxmin, 3 * ng), "group_boxmax": take(d.group_boxmax, 3 * ng),
+            "group_directions": take(d.group_directions, 3 * ng), "group_children": take(d.group_children, 2 * ng),
+            "group_objects": take(d.group_objects, 2 * ng),
+        }
+        hm = np.ctypeslib.as_array(d.group_hitmiss, shape=(8, stride, 2)) if stride else np.zeros((8, 0, 2), np.float32)
+        for code in range(8):
+            out[f"group_hitmiss_{code}"] = hm[code, :ng].reshape(-1).copy()
+        return out
+
+    def default_view(self) -> N.HostView:
+        view = N.HostView()
+        self._lib.shray_host_default_view(self._handle, C.byref(view))
+        return view
+
+    def frame_params(self, width: int, height: int, view: N.HostView | None = None, *, material: int | None = None,
+                     diffuse: int | None = None) -> N.FrameParams:
+        """Frame block for a width x height frame (reference ray.cpp:648-704).  `material`
+        indexes the reference's table: 0 = gold ... 6 = glazed plaster (ray.cpp:54-65)."""
+        if view is None:
+            view = self.default_view()
+        if material is not None:
+            view.which_material = material
+        if diffuse is not None:
+            view.which_diffuse_color = diffuse
+        params = N.FrameParams()
+        if self._lib.shray_host_frame_params(self._handle, C.byref(view), width, height, C.byref(params)) != 0:
+            raise RuntimeError("frame parameter computation failed")
+        return params

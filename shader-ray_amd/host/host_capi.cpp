@@ -1,0 +1,130 @@
+// host_capi.cpp -- extern "C" view of the host layer (include/shader_ray_host.h).
+#include <chrono>
+#include <cstring>
+#include <memory>
+
+#include "bvh.h"
+#include "frame-params.h"
+#include "host-log.h"
+#include "shader_ray_host.h"
+#include "world.h"
+
+bool g_host_quiet = false;
+
+struct shray_host_world {
+    world_ptr w;
+    std::unique_ptr<scene_shader_data> flat;
+    bvh_build_stats stats;
+    double load_seconds = 0;
+};
+
+extern "C" {
+
+void shray_host_set_quiet(int quiet) { g_host_quiet = quiet != 0; }
+
+int shray_host_load_world(const char *filename, shray_host_world **out_world)
+{
+    if (!filename || !out_world)
+        return -1;
+    *out_world = nullptr;
+    const auto then = std::chrono::steady_clock::now();
+    world_ptr w = load_world(filename);
+    if (!w)
+        return -1;
+    auto *hw = new shray_host_world;
+    hw->w = w;
+    hw->stats = bvh_stats();
+    hw->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - then).count();
+    *out_world = hw;
+    return 0;
+}
+
+void shray_host_free_world(shray_host_world *world) { delete world; }
+
+int shray_host_get_world_info(const shray_host_world *world, shray_host_world_info *info)
+{
+    if (!world || !info)
+        return -1;
+    memset(info, 0, sizeof(*info));
+    const world_ptr &w = world->w;
+    info->triangle_count = w->triangle_count;
+    info->independent_vertex_count = (int32_t)w->triangles->vertices.size();
+    info->scene_center[0] = w->scene_center.x;
+    info->scene_center[1] = w->scene_center.y;
+    info->scene_center[2] = w->scene_center.z;
+    info->scene_extent = w->scene_extent;
+    info->node_count = world->stats.node_count;
+    info->leaf_count = world->stats.leaf_count;
+    info->max_level = world->stats.max_level;
+    info->large_leaves = world->stats.large_leaves;
+    info->build_seconds = world->load_seconds;
+    return 0;
+}
+
+int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width, shray_scene_desc *desc)
+{
+    if (!world || !desc || data_texture_width == 0)
+        return -1;
+    world->flat.reset(new scene_shader_data);
+    scene_shader_data &d = *world->flat;
+    get_shader_data(world->w, d, data_texture_width);
+
+    memset(desc, 0, sizeof(*desc));
+    desc->struct_size = (uint32_t)sizeof(*desc);
+    desc->data_texture_width = data_texture_width;
+    desc->vertex_count = d.vertex_count;
+    desc->vertex_data_rows = d.vertex_data_rows;
+    desc->vertex_positions = d.vertex_positions;
+    desc->vertex_normals = d.vertex_normals;
+    desc->vertex_colors = d.vertex_colors;
+    desc->group_count = d.group_count;
+    desc->group_data_rows = d.group_data_rows;
+    desc->tree_root = d.tree_root;
+    desc->group_boxmin = d.group_boxmin;
+    desc->group_boxmax = d.group_boxmax;
+    desc->group_directions = d.group_directions;
+    desc->group_children = d.group_children;
+    desc->group_hitmiss = d.group_hitmiss;
+    desc->group_objects = d.group_objects;
+    return 0;
+}
+
+int shray_host_default_view(const shray_host_world *world, shray_host_view *view)
+{
+    if (!world || !view)
+        return -1;
+    const view_state s = default_view_state(world->w);
+    view->fov = s.fov;
+    view->zoom = s.zoom;
+    memcpy(view->object_rotation, s.object_rotation, sizeof(view->object_rotation));
+    view->object_position[0] = s.object_position.x;
+    view->object_position[1] = s.object_position.y;
+    view->object_position[2] = s.object_position.z;
+    memcpy(view->light_rotation, s.light_rotation, sizeof(view->light_rotation));
+    view->which = s.which;
+    view->which_material = s.which_material;
+    view->which_diffuse_color = s.which_diffuse_color;
+    return 0;
+}
+
+int shray_host_frame_params(shray_host_world *world, const shray_host_view *view, int width, int height,
+                            shray_frame_params *params)
+{
+    if (!world || !view || !params || width <= 0 || height <= 0)
+        return -1;
+    if (view->which_material < 0 || view->which_diffuse_color < 0)
+        return -1;
+    view_state s;
+    s.fov = view->fov;
+    s.zoom = view->zoom;
+    memcpy(s.object_rotation, view->object_rotation, sizeof(s.object_rotation));
+    s.object_position = vec3(view->object_position[0], view->object_position[1], view->object_position[2]);
+    memcpy(s.light_rotation, view->light_rotation, sizeof(s.light_rotation));
+    s.which = view->which;
+    s.which_material = view->which_material;
+    s.which_diffuse_color = view->which_diffuse_color;
+    make_frame_params(world->w, s, width, height, params);
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,88 @@
+// world.h -- scene container, loader entry point and the flattened
+// "shader data" arrays that cross into the GPU path.
+//
+// Public names and field meanings follow the reference (world.h:28-95) so
+// that code written against it keeps compiling:
+//   struct camera, struct world, world_ptr, load_world(),
+//   struct scene_shader_data, get_shader_data(), trace_image().
+#pragma once
+
+#include <memory>
+#include <string>
+
+#include "geometry.h"
+#include "group.h"
+#include "triangle-set.h"
+#include "vectormath.h"
+
+struct camera {
+    float fov;   // full horizontal view angle, radians
+};
+
+struct world {
+    int triangle_count;
+    triangle_set_ptr triangles;   // traced only through `root`
+
+    group *root;
+
+    vec3 scene_center;
+    float scene_extent;   // diameter of the bounding sphere about scene_center
+
+    camera cam;
+    int xsub, ysub;
+
+    float camera_matrix[16];
+    float camera_normal_matrix[16];
+
+    float object_matrix[16];
+    float object_inverse[16];
+    float object_normal_matrix[16];
+    float object_normal_inverse[16];
+
+    world();
+    ~world();
+    world(const world &) = delete;
+    world &operator=(const world &) = delete;
+};
+
+typedef std::shared_ptr<world> world_ptr;
+
+// Loads a .trisrc or .obj file, computes centre / extent, builds the BVH.
+// Returns nullptr (after a message on stderr) on any failure (world.cpp:46-134).
+world_ptr load_world(const std::string &filename);
+
+// Declared by the reference (world.h:65) but never defined there.  Here it
+// renders the world through the HIP layer (shader_ray_hip.h) with the
+// reference's default material and an all-white environment unless one was
+// installed with set_trace_environment(); `image` receives width*height RGB8,
+// top row first.  Implemented in tools/trace_image.cpp (needs the HIP library).
+void trace_image(int width, int height, float aspect, unsigned char *image, const world_ptr Wd, const vec3 &light_dir);
+
+// The arrays the fragment shader samples, exactly as the reference lays them
+// out (world.h:68-93, world.cpp:298-347).  All float32; every array is padded
+// to data_texture_width * rows elements (padding is zero here).
+struct scene_shader_data {
+    unsigned int vertex_count;
+    unsigned int vertex_data_rows;
+    float *vertex_positions;   // float3 per vertex, three vertices per triangle
+    float *vertex_colors;      // float3
+    float *vertex_normals;     // float3
+
+    int group_count;
+    int group_data_rows;
+    int tree_root;
+    float *group_boxmin;       // float3 per node
+    float *group_boxmax;       // float3 per node
+    float *group_directions;   // float3 per node (branches only)
+    float *group_children;     // float2 per node; 2147483648 for leaves
+
+    float *group_hitmiss;      // 8 tables of float2 (hit, miss); 2147483648 terminates
+    float *group_objects;      // float2 per node (start, count); 0,0 for branches
+
+    scene_shader_data();
+    ~scene_shader_data();
+    scene_shader_data(const scene_shader_data &) = delete;
+    scene_shader_data &operator=(const scene_shader_data &) = delete;
+};
+
+void get_shader_data(world_ptr w, scene_shader_data &data, unsigned int data_texture_width);

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): bunny-class mesh (69,168 triangles, written as
+trisrc text and loaded through the real parser + BVH builder), seeded HDR sky environment,
+1920x1080, 1 spp, default gold material, 3 bounces.  A "step" is one frame: every rank
+renders its interleaved tiles with the HIP kernel and (N > 1) the packed tile buffers are
+gathered to rank 0 over RCCL and de-interleaved.  Scene and environment are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+For N > 1 launch as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WIDTH, HEIGHT, SPP = 1920, 1080, 1
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
+    """The CPU oracle (oracle/, a port of the shader: the reference has no CPU tracer) on the
+    same frame, all host cores; repeated until ~budget_s of wall time."""
+    import oracle
+    threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)
+    first = time.perf_counter() - t0
+    reps = max(1, min(20, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(WIDTH * HEIGHT * SPP / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"the full {WIDTH}x{HEIGHT} frame of the same workload, {reps} repetitions ({dt:.2f} s each), "
+                      f"CPU oracle with {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from __graft_entry__ import load_package
+    import helpers
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    distributed = world_size > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_package()
+    # rank 0 generates the scene file once; the others wait for it
+    if rank == 0:
+        path = helpers.bunny_trisrc()
+    if distributed:
+        dist.barrier()
+    path = helpers.bunny_trisrc()
+    world = pkg.World(path)
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(2048)
+    params = world.frame_params(WIDTH, HEIGHT, material=0)
+    scene = pkg.Scene(desc, env, device=local_rank)
+    scene.set_kernel(args.kernel)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    from shader_ray_amd import multigpu
+
+    tile = multigpu.DEFAULT_TILE
+
+    def render_tiles(tile_set, out):
+        scene.render_into(params, WIDTH, HEIGHT, SPP, out.data_ptr(), stream, tile_set)
+
+    frame_out = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
+
+    def step():
+        if distributed:
+            return multigpu.render_frame_distributed(render_tiles, WIDTH, HEIGHT, tile, tile, device=device)
+        scene.render_into(params, WIDTH, HEIGHT, SPP, frame_out.data_ptr(), stream, None)
+        return frame_out
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+
+    # per-launch kernel time: HIP events on the stream the kernel is launched on (N = 1)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if not distributed:
+            starts[k].record()
+        step()
+        if not distributed:
+            stops[k].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        rays = WIDTH * HEIGHT * SPP * args.steps
+        result = {
+            "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling",
+            "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
+                                   "2048x1024 HDR sky, 1920x1080, 1 spp, gold, 3 bounces (BASELINE configs[1])",
+                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": "stack" if args.kernel == 0 else "threaded",
+                       "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu"},
+        }
+    if not distributed:
+        kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        _, counters = scene.render_counters(params, WIDTH, HEIGHT, SPP, want_image=False)
+        algo_bytes = pkg.tracer.algorithmic_bytes(counters, WIDTH * HEIGHT, normals_fp16=True)
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                              "algorithmic_bytes_per_launch": algo_bytes,
+                              "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
+                              "kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5)}
+        result["counters"] = counters
+        # the C ABI's blocking form copies the frame to host memory: PCIe-inclusive rate, for the record
+        t0 = time.perf_counter()
+        for _ in range(5):
+            scene.render(params, WIDTH, HEIGHT, SPP)
+        result["host_readback_mrays"] = round(WIDTH * HEIGHT * SPP * 5 / (time.perf_counter() - t0) / 1e6, 2)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pkg, desc, env, params)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

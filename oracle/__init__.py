@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE: ctypes access to the CPU restatement (oracle/shader_oracle.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
+the product package (shader-ray_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libshader_oracle.so")
+REF_HOST = os.path.join(HERE, "_ref", "ref_host")
+
+_lib = None
+
+
+def build(ref: bool = True) -> None:
+    subprocess.run(["make", "-C", HERE, "oracle"] + (["ref"] if ref else []), check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build(ref=False)
+        _lib = C.CDLL(LIB)
+        _lib.shray_oracle_render.restype = C.c_int
+        _lib.shray_oracle_filmic.restype = C.c_float
+        _lib.shray_oracle_filmic.argtypes = [C.c_float]
+        _lib.shray_oracle_half.restype = C.c_float
+        _lib.shray_oracle_half.argtypes = [C.c_float]
+    return _lib
+
+
+def render(desc, env: np.ndarray, params, width: int, height: int, spp: int = 1, rows=None, threads: int = 0):
+    """Full-frame RGBA float32 [height, width, 4] (row 0 = bottom) plus a counters dict.
+    `desc`/`params` are the ctypes structs of shader-ray_amd/_native.py (same C layout)."""
+    lib = load()
+    env = np.ascontiguousarray(env, dtype=np.float32)
+    eh, ew, _ = env.shape
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    r0, r1 = (0, height) if rows is None else rows
+    counters = (C.c_uint64 * 8)()
+    rc = lib.shray_oracle_render(C.byref(desc), env.ctypes.data_as(C.c_void_p), C.c_int(ew), C.c_int(eh),
+                                 C.byref(params), C.c_int(width), C.c_int(height), C.c_int(spp),
+                                 C.c_int(r0), C.c_int(r1), C.c_int(threads),
+                                 out.ctypes.data_as(C.c_void_p), C.byref(counters))
+    if rc != 0:
+        raise RuntimeError("oracle rejected its arguments")
+    names = ("node_visits", "leaf_visits", "triangle_tests", "shaded_hits", "env_lookups", "traversals",
+             "bad_hits", "samples")
+    return out, dict(zip(names, (int(c) for c in counters)))
+
+
+def filmic(c: float) -> float:
+    return float(load().shray_oracle_filmic(C.c_float(c)))
+
+
+def half(f: float) -> float:
+    return float(load().shray_oracle_half(C.c_float(f)))
+
+
+def schlick(cspec, v, r):
+    out = (C.c_float * 3)()
+    load().shray_oracle_schlick((C.c_float * 3)(*cspec), (C.c_float * 3)(*v), (C.c_float * 3)(*r), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def primary_ray(params, u: float, v: float):
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    load().shray_oracle_primary_ray(C.byref(params), C.c_float(u), C.c_float(v), o, d)
+    return np.array(o[:], dtype=np.float32), np.array(d[:], dtype=np.float32)

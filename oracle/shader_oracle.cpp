@@ -1,0 +1,560 @@
+// shader_oracle.cpp -- CPU restatement of shader-ray's per-pixel path.
+//
+// *** TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+// *** cpu_baseline leg may load this.  The product path never routes through it.
+//
+// PARITY STATUS: the per-pixel path of the reference exists only as GLSL
+// (raytracer.vs, raytracer.es.fs), which cannot execute in this environment,
+// and the reference ships no tests, golden images or known-answer vectors for
+// it: THE PER-PIXEL PART OF THIS ORACLE IS "PARITY UNPINNED" by the reference.
+// What pins it instead: (1) its inputs -- the flattened arrays and frame
+// parameters -- are checked bit-for-bit against the compiled reference
+// (oracle/_ref, tests/golden); (2) analytic known-answer tests written from
+// the shader text (tests/test_oracle_kat.py).
+//
+// Every function below cites the shader lines it restates (file:line into the
+// reference repository; "fs" = raytracer.es.fs, "vs" = raytracer.vs).
+//
+// Arithmetic contract (shared with the HIP kernel):
+//   * IEEE float32 throughout: the host prepends "#version 140" (ray.cpp:401),
+//     desktop GLSL, where mediump/highp are all fp32.  One rounding per
+//     operation, no FMA contraction (-ffp-contract=off), IEEE divide and sqrt.
+//   * dot(a,b)   = a.x*b.x + a.y*b.y + a.z*b.z, left to right
+//     cross      = the usual three differences of products
+//     normalize  = v / sqrt(dot(v,v))                    (GLSL 1.40 spec 8.4)
+//     reflect    = I - (2*dot(N,I))*N                    (GLSL 1.40 spec 8.4)
+//     max(x,y)   = x < y ? y : x;  min(x,y) = y < x ? y : x   (spec 8.3)
+//     mat4*vec4  = sum over columns, x..w in order
+//   * atan(y,x) -> atan2f, acos -> acosf with the argument clamped to [-1,1]
+//     (GLSL leaves |x|>1 undefined, fs:130), pow -> powf.  These three are the
+//     only operations not bit-reproducible across libm/ocml; they feed only
+//     continuous quantities, hence the 1e-4 relative tolerance.
+//   * data textures are NEAREST-filtered (ray.cpp:351-352) and index_to_sample
+//     (fs:239-245) lands in texel (which mod W, which div W): plain array reads.
+//     All indices are float32 values (exact below 2^24).
+//   * normals are stored as GL_RGB16F (ray.cpp:474): rounded to binary16
+//     (round-to-nearest-even) when params.normals_fp16 is set.
+//   * the environment is kept float32 (the reference uploads it with an
+//     unsized GL_RGB internal format, ray.cpp:508, which would usually clamp to
+//     8 bits; a literal evaluation of the shader sees floats).  Lookup =
+//     level-0 bilinear with full float weights, REPEAT wrap in s and t
+//     (textureGrad with zero gradients, fs:153; MAG LINEAR ray.cpp:505).
+//   * primary rays: the vertex shader (vs:39-60) is evaluated at the pixel
+//     centre instead of being interpolated from the quad corners; the two
+//     agree up to float rounding because all four corner rays have one length.
+//     Row 0 of the output is the BOTTOM row (v = 0, vs:43-44).
+//   * spp > 1 (not in the reference except which==5, fs:654-673): sample s of
+//     n uses sub-pixel offset ((s+.5)/n, bitreverse32(s)*2^-32 + .5/n);
+//     linear radiance is summed in sample order, divided by n, then tone
+//     mapped once -- the same order of operations as fs:669-676.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "shader_ray_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GLSL-ish
+struct vec3 {
+    float x, y, z;
+};
+inline vec3 V(float x, float y, float z) { return vec3{x, y, z}; }
+inline vec3 operator+(vec3 a, vec3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(vec3 a, vec3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 operator*(vec3 a, vec3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator*(vec3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator*(float s, vec3 a) { return V(s * a.x, s * a.y, s * a.z); }
+inline vec3 operator/(vec3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(vec3 a, vec3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline vec3 normalize(vec3 a) { return a / sqrtf(dot(a, a)); }
+inline vec3 reflect(vec3 I, vec3 N) { return I - (2.0f * dot(N, I)) * N; }
+inline float gl_max(float x, float y) { return x < y ? y : x; }
+inline float gl_min(float x, float y) { return y < x ? y : x; }
+
+// mat4 * vec4(v, w), column-major storage
+inline vec3 transform(const float m[16], vec3 v, float w)
+{
+    return V(m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * w,
+             m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * w,
+             m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * w);
+}
+
+// binary32 -> binary16 -> binary32, round to nearest even, IEEE subnormals
+float round_through_half(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t mag = u & 0x7fffffffu;
+    float out;
+    if (mag >= 0x7f800000u) {              // inf / nan stay
+        return f;
+    } else if (mag >= 0x477ff000u) {       // rounds to >= 65520 -> inf
+        mag = 0x7f800000u;
+    } else if (mag < 0x38800000u) {        // below 2^-14: half subnormal, quantum 2^-24
+        float a;
+        memcpy(&a, &mag, 4);
+        const float q = a * 16777216.0f;   // exact scaling by 2^24
+        const float r = nearbyintf(q);     // default rounding mode = nearest even
+        a = r / 16777216.0f;
+        memcpy(&mag, &a, 4);
+    } else {                               // normal half: keep 10 fraction bits
+        const uint32_t lsb = (mag >> 13) & 1u;
+        mag += 0xfffu + lsb;
+        mag &= ~0x1fffu;
+    }
+    mag |= sign;
+    memcpy(&out, &mag, 4);
+    return out;
+}
+
+// --------------------------------------------------------------------- scene
+struct Scene {
+    uint32_t width;            // data_texture_width
+    int group_rows;
+    float tree_root;
+    const float *positions;
+    std::vector<float> normals;   // possibly fp16-rounded copy
+    const float *boxmin, *boxmax, *hitmiss, *objects;
+    const float *env;
+    int env_w, env_h;
+};
+
+struct Counters {
+    uint64_t node_visits = 0, leaf_visits = 0, triangle_tests = 0, shaded_hits = 0, env_lookups = 0, traversals = 0,
+             bad_hits = 0;
+};
+
+struct Ctx {
+    const Scene *scene;
+    const shray_frame_params *p;
+    Counters c;
+};
+
+struct ray {   // fs:58-63 (differentials only matter for which in {1,2,3}; not carried here)
+    vec3 P, D;
+};
+
+struct surface_hit {   // fs:108-113
+    float t, which;
+    vec3 uvw;
+};
+
+const float infinitely_far = 10000000.0f;   // fs:115
+const float pi = 3.14159265259f;            // fs:116 (rounds to the float nearest pi)
+const float tau = 2 * pi;                   // fs:117
+const float terminator = 16777215.0f;       // fs:384
+
+struct range {   // fs:168-171
+    float t0, t1;
+};
+inline range make_range(float t0, float t1) { return range{t0, t1}; }             // fs:173-179
+inline range range_intersect(range a, range b)                                     // fs:186-191
+{
+    return make_range(gl_max(a.t0, b.t0), gl_min(a.t1, b.t1));
+}
+inline bool range_is_empty(range r) { return r.t0 >= r.t1; }                       // fs:193-196
+
+// fs:200-217 -- slab test with a true division per plane
+range range_intersect_box(vec3 boxmin, vec3 boxmax, const ray &theray, range prevr)
+{
+    float t0, t1;
+    t0 = (boxmin.x - theray.P.x) / theray.D.x;
+    t1 = (boxmax.x - theray.P.x) / theray.D.x;
+    range r0 = range_intersect(prevr, (theray.D.x >= 0.0f) ? make_range(t0, t1) : make_range(t1, t0));
+    t0 = (boxmin.y - theray.P.y) / theray.D.y;
+    t1 = (boxmax.y - theray.P.y) / theray.D.y;
+    range r1 = range_intersect(r0, (theray.D.y >= 0.0f) ? make_range(t0, t1) : make_range(t1, t0));
+    t0 = (boxmin.z - theray.P.z) / theray.D.z;
+    t1 = (boxmax.z - theray.P.z) / theray.D.z;
+    range r2 = range_intersect(r1, (theray.D.z >= 0.0f) ? make_range(t0, t1) : make_range(t1, t0));
+    return r2;
+}
+
+inline vec3 fetch3(const float *a, float index)
+{
+    const size_t i = (size_t)index;
+    return V(a[3 * i], a[3 * i + 1], a[3 * i + 2]);
+}
+
+struct group {   // fs:219-227
+    bool is_branch;
+    float start, count;
+    vec3 boxmin, boxmax;
+    float hit_next, miss_next;
+};
+
+// fs:247-270
+group get_group(Ctx &cx, float which, float hitmiss_offset)
+{
+    const Scene &s = *cx.scene;
+    group g;
+    g.boxmin = fetch3(s.boxmin, which);
+    g.boxmax = fetch3(s.boxmax, which);
+    const size_t link = (size_t)(which + hitmiss_offset);
+    g.hit_next = s.hitmiss[2 * link];
+    g.miss_next = s.hitmiss[2 * link + 1];
+    g.is_branch = (g.hit_next != g.miss_next);
+    g.start = g.count = 0;
+    if (!g.is_branch) {
+        const size_t i = (size_t)which;
+        g.start = s.objects[2 * i];
+        g.count = s.objects[2 * i + 1];
+        cx.c.leaf_visits++;
+    }
+    return g;
+}
+
+// fs:297-346
+void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surface_hit &hit)
+{
+    cx.c.triangle_tests++;
+    const Scene &s = *cx.scene;
+    const vec3 v0 = fetch3(s.positions, which * 3.0f + 0.0f);
+    const vec3 v1 = fetch3(s.positions, which * 3.0f + 1.0f);
+    const vec3 v2 = fetch3(s.positions, which * 3.0f + 2.0f);
+
+    const vec3 e0 = v1 - v0;
+    const vec3 e1 = v0 - v2;
+    const vec3 M = cross(e1, theray.D);
+    const float det = dot(e0, M);
+    const float epsilon = 0.0000001f;
+    if (det > -epsilon && det < epsilon)
+        return;
+    const float inv_det = 1.0f / det;
+
+    const vec3 T = theray.P - v0;
+    const vec3 Q = cross(T, e0);
+    const float d = -dot(e1, Q) * inv_det;
+    if (d > hit.t)
+        return;
+    if (d < r.t0 || d > r.t1)
+        return;
+    const float u = dot(T, M) * inv_det;
+    if (u < 0.0f || u > 1.0f)
+        return;
+    const float v = dot(theray.D, Q) * inv_det;
+    if (v < 0.0f || u + v > 1.0f)
+        return;
+    hit.which = which;
+    hit.t = d;
+    hit.uvw.x = 1.0f - u - v;
+    hit.uvw.y = u;
+    hit.uvw.z = v;
+}
+
+// fs:386-443, CONSTANT_LENGTH_LOOPS branch
+void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surface_hit &hit)
+{
+    cx.c.traversals++;
+    const Scene &s = *cx.scene;
+    const int max_bvh_iterations = cx.p->max_bvh_iterations;   // fs:381
+    const float max_leaf_tests = (float)cx.p->max_leaf_tests;  // fs:382
+    float g = root;
+    const float xd = (theray.D.x > 0.0f) ? 1.0f : 0.0f;
+    const float yd = (theray.D.y > 0.0f) ? 2.0f : 0.0f;
+    const float zd = (theray.D.z > 0.0f) ? 4.0f : 0.0f;
+    const float offset = (xd + yd + zd) * float(s.group_rows) * float(s.width);
+
+    for (int i = 0; i < max_bvh_iterations; i++) {
+        cx.c.node_visits++;
+        group gg = get_group(cx, g, offset);
+        range r = range_intersect_box(gg.boxmin, gg.boxmax, theray, prevr);
+        if ((!range_is_empty(r)) && (r.t0 < hit.t)) {
+            if (!gg.is_branch) {
+                for (float j = 0.0f; j < max_leaf_tests; j++) {
+                    if (j >= gg.count)
+                        break;
+                    triangle_intersect(cx, gg.start + j, theray, r, hit);
+                }
+            }
+            g = gg.hit_next;
+        } else {
+            g = gg.miss_next;
+        }
+        if (g >= terminator)
+            return;
+        if (i == max_bvh_iterations - 1) {   // fs:436-438, set_bad_hit(hit, 1, 0, 0) fs:162-166
+            hit.t = -1.0f;
+            hit.uvw = V(1.0f, 0.0f, 0.0f);
+        }
+    }
+}
+
+inline surface_hit surface_hit_init() { return surface_hit{infinitely_far, -1.0f, V(1, 0, 0)}; }   // fs:157-160
+
+// fs:98-106 (P and D only)
+inline ray ray_transform(const ray &r, const float matrix[16], const float normal_matrix[16])
+{
+    return ray{transform(matrix, r.P, 1.0f), transform(normal_matrix, r.D, 0.0f)};
+}
+
+// fs:288-295
+vec3 triangle_interpolate_normal(const Scene &s, float which, vec3 uvw)
+{
+    const vec3 n0 = fetch3(s.normals.data(), which * 3.0f + 0.0f);
+    const vec3 n1 = fetch3(s.normals.data(), which * 3.0f + 1.0f);
+    const vec3 n2 = fetch3(s.normals.data(), which * 3.0f + 2.0f);
+    return n0 * uvw.x + n1 * uvw.y + n2 * uvw.z;
+}
+
+// fs:447-472
+vec3 approximate_diffuse(Ctx &cx, vec3 point, vec3 normal)
+{
+    const shray_frame_params &p = *cx.p;
+    const vec3 light_dir = V(p.light_dir[0], p.light_dir[1], p.light_dir[2]);
+    const float lcos = gl_max(0.0f, dot(normal, light_dir));
+    const vec3 light_diffuse = V(1.0f, 1.0f, 1.0f) * lcos;   // light_color fs:25
+    vec3 diffuse = V(0.0f, 0.0f, 0.0f);                      // ambient
+    if (p.cast_shadows) {
+        surface_hit shadow_hit = surface_hit_init();
+        const ray world_shadowray{point, light_dir};
+        const ray object_shadowray = ray_transform(world_shadowray, p.object_matrix, p.object_normal_matrix);
+        group_intersect(cx, cx.scene->tree_root, object_shadowray, make_range(0.0f, 100000000.0f), shadow_hit);
+        if (shadow_hit.t >= infinitely_far)
+            diffuse = diffuse + light_diffuse;
+    } else {
+        diffuse = diffuse + light_diffuse;
+    }
+    return diffuse;
+}
+
+// fs:479-482
+inline vec3 f_schlick_vr(vec3 cspec, vec3 v, vec3 r)
+{
+    const float w = powf(dot(v, r) * .5f + .5f, 5.0f);
+    return cspec + (V(1.0f, 1.0f, 1.0f) - cspec) * w;
+}
+
+// fs:484-522
+int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3 &object_specular, vec3 &normal,
+                        ray &reflected)
+{
+    const shray_frame_params &p = *cx.p;
+    surface_hit shading = surface_hit_init();
+    const ray objectray = ray_transform(worldray, p.object_matrix, p.object_normal_matrix);
+    group_intersect(cx, cx.scene->tree_root, objectray, make_range(0.0f, 100000000.0f), shading);
+
+    if (shading.t >= infinitely_far)
+        return 0;
+    if (shading.t == -1.0f) {
+        object_diffuse = shading.uvw;
+        object_specular = V(0, 0, 0);
+        return 2;
+    }
+
+    // shade(), fs:362-377; hit.which >= 0 always holds here
+    cx.c.shaded_hits++;
+    const vec3 object_normal = triangle_interpolate_normal(*cx.scene, shading.which, shading.uvw);
+    const vec3 object_color = V(1.0f, 1.0f, 1.0f);
+
+    vec3 world_normal = transform(p.object_normal_inverse, object_normal, 0.0f);
+    if (dot(world_normal, worldray.D) > 0.0f)
+        world_normal = world_normal * -1.0f;
+
+    // ray_transfer fs:65-81, ray_reflect fs:83-96 (P, D only)
+    ray transferred{worldray.P + worldray.D * shading.t, worldray.D};
+    reflected.D = reflect(transferred.D, world_normal);
+    reflected.P = transferred.P + world_normal * .0001f;
+
+    object_specular = f_schlick_vr(V(p.specular_color[0], p.specular_color[1], p.specular_color[2]), worldray.D, reflected.D);
+    object_diffuse = V(p.diffuse_color[0], p.diffuse_color[1], p.diffuse_color[2]) * object_color;
+    normal = world_normal;
+    return 1;
+}
+
+// fs:127-155, which == 0 branch: level-0 bilinear, REPEAT
+vec3 sample_environment(Ctx &cx, const ray &r)
+{
+    cx.c.env_lookups++;
+    const Scene &sc = *cx.scene;
+    const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
+    const float s = 1.0f + atan2f(-r.D.z, r.D.x) / tau;
+    const float t = 1.0f - acosf(dy) / pi;
+    const float fw = (float)sc.env_w, fh = (float)sc.env_h;
+    const float u = s * fw - 0.5f;
+    const float v = t * fh - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    auto wrap = [](float f, int n) {
+        int i = (int)f % n;
+        return i < 0 ? i + n : i;
+    };
+    const int i0 = wrap(fu, sc.env_w), i1 = wrap(fu + 1.0f, sc.env_w);
+    const int j0 = wrap(fv, sc.env_h), j1 = wrap(fv + 1.0f, sc.env_h);
+    auto texel = [&](int i, int j) {
+        const float *px = sc.env + 3 * ((size_t)j * sc.env_w + i);
+        return V(px[0], px[1], px[2]);
+    };
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return texel(i0, j0) * w00 + texel(i1, j0) * w10 + texel(i0, j1) * w01 + texel(i1, j1) * w11;
+}
+
+// fs:552-582
+vec3 trace(Ctx &cx, ray worldray)
+{
+    vec3 accumulated = V(0, 0, 0);
+    vec3 modulation = V(1, 1, 1);
+    for (int i = 0; i < cx.p->bounce_count; i++) {
+        ray reflected{};
+        vec3 object_diffuse{}, object_specular{}, normal{};
+        const int hit_something = intersect_and_shade(cx, worldray, object_diffuse, object_specular, normal, reflected);
+        if (hit_something == 0)
+            break;
+        if (hit_something == 2) {
+            cx.c.bad_hits++;
+            return object_diffuse;
+        }
+        if (object_diffuse.x > 0.0f && object_diffuse.y > 0.0f && object_diffuse.z > 0.0f) {
+            const vec3 diffuse_irradiance = approximate_diffuse(cx, reflected.P, normal);
+            accumulated = accumulated + modulation * object_diffuse * diffuse_irradiance;
+        }
+        modulation = modulation * object_specular;
+        worldray = reflected;
+    }
+    const vec3 background_color = sample_environment(cx, worldray);
+    return accumulated + modulation * background_color;
+}
+
+// fs:527-531
+inline float filmic(float c)
+{
+    const float x = gl_max(0.0f, c - 0.004f);
+    return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
+}
+
+inline uint32_t bitreverse32(uint32_t v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+}
+
+// vs:39-60 evaluated at image-plane position (u, v), then fs:617-619
+ray primary_ray(const shray_frame_params &p, float u, float v)
+{
+    const vec3 eye_d = normalize(V(p.image_plane_width * (u - 0.5f), p.image_plane_width * (v - 0.5f) * p.aspect, -1.0f));
+    ray world = ray_transform(ray{V(0, 0, 0), eye_d}, p.camera_matrix, p.camera_normal_matrix);
+    world.D = normalize(world.D);
+    return world;
+}
+
+void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float out[4])
+{
+    const shray_frame_params &p = *cx.p;
+    vec3 sum = V(0, 0, 0);
+    for (int s = 0; s < spp; s++) {
+        const float ox = ((float)s + 0.5f) / (float)spp;
+        const float oy = (float)bitreverse32((uint32_t)s) * 2.3283064365386963e-10f + 0.5f / (float)spp;
+        const float u = ((float)px + ox) / (float)width;
+        const float v = ((float)py + oy) / (float)height;
+        const vec3 radiance = trace(cx, primary_ray(p, u, v));
+        sum = (spp == 1) ? radiance : sum + radiance;
+    }
+    vec3 result = (spp == 1) ? sum : sum / (float)spp;
+    if (p.tonemap)   // fs:675-679, use_filmic fs:524
+        result = V(filmic(result.x), filmic(result.y), filmic(result.z));
+    out[0] = result.x;
+    out[1] = result.y;
+    out[2] = result.z;
+    out[3] = 1.0f;
+}
+
+}   // namespace
+
+extern "C" {
+
+// Renders rows [row_begin, row_end) (row 0 = bottom) of a width x height frame
+// into rgba_out (full-frame RGBA float32, row-major from the bottom; only the
+// requested rows are written).  threads <= 0 = hardware_concurrency().
+// Returns 0, or -1 on bad arguments.
+int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int env_w, int env_h,
+                        const shray_frame_params *params, int width, int height, int spp, int row_begin, int row_end,
+                        int threads, float *rgba_out, shray_counters *counters_out)
+{
+    if (!desc || !env_rgb || !params || !rgba_out || width <= 0 || height <= 0 || spp <= 0 || env_w <= 0 || env_h <= 0)
+        return -1;
+    if (params->which != 0)
+        return -1;
+    row_begin = std::max(0, row_begin);
+    row_end = std::min(height, row_end);
+
+    Scene scene;
+    scene.width = desc->data_texture_width;
+    scene.group_rows = desc->group_data_rows;
+    scene.tree_root = (float)desc->tree_root;
+    scene.positions = desc->vertex_positions;
+    scene.normals.assign(desc->vertex_normals, desc->vertex_normals + 3 * (size_t)desc->vertex_count);
+    if (params->normals_fp16)
+        for (float &n : scene.normals)
+            n = round_through_half(n);
+    scene.boxmin = desc->group_boxmin;
+    scene.boxmax = desc->group_boxmax;
+    scene.hitmiss = desc->group_hitmiss;
+    scene.objects = desc->group_objects;
+    scene.env = env_rgb;
+    scene.env_w = env_w;
+    scene.env_h = env_h;
+
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nthreads = std::max(1, std::min(nthreads, std::max(1, row_end - row_begin)));
+    std::vector<Counters> per_thread(nthreads);
+    std::atomic<int> next_row(row_begin);
+    auto worker = [&](int tid) {
+        Ctx cx{&scene, params, Counters()};
+        for (;;) {
+            const int py = next_row.fetch_add(1);
+            if (py >= row_end)
+                break;
+            for (int px = 0; px < width; px++)
+                shade_pixel(cx, px, py, width, height, spp, rgba_out + 4 * ((size_t)py * width + px));
+        }
+        per_thread[tid] = cx.c;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; t++)
+        pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : pool)
+        t.join();
+
+    if (counters_out) {
+        memset(counters_out, 0, sizeof(*counters_out));
+        for (const Counters &c : per_thread) {
+            counters_out->node_visits += c.node_visits;
+            counters_out->leaf_visits += c.leaf_visits;
+            counters_out->triangle_tests += c.triangle_tests;
+            counters_out->shaded_hits += c.shaded_hits;
+            counters_out->env_lookups += c.env_lookups;
+            counters_out->traversals += c.traversals;
+            counters_out->bad_hits += c.bad_hits;
+        }
+        counters_out->samples = (uint64_t)width * (uint64_t)(row_end - row_begin) * (uint64_t)spp;
+    }
+    return 0;
+}
+
+// Pieces exposed for the known-answer tests.
+float shray_oracle_filmic(float c) { return filmic(c); }
+float shray_oracle_half(float f) { return round_through_half(f); }
+void shray_oracle_schlick(const float cspec[3], const float v[3], const float r[3], float out[3])
+{
+    const vec3 f = f_schlick_vr(V(cspec[0], cspec[1], cspec[2]), V(v[0], v[1], v[2]), V(r[0], r[1], r[2]));
+    out[0] = f.x; out[1] = f.y; out[2] = f.z;
+}
+void shray_oracle_primary_ray(const shray_frame_params *p, float u, float v, float origin[3], float direction[3])
+{
+    const ray r = primary_ray(*p, u, v);
+    origin[0] = r.P.x; origin[1] = r.P.y; origin[2] = r.P.z;
+    direction[0] = r.D.x; direction[1] = r.D.y; direction[2] = r.D.z;
+}
+
+}   // extern "C"

@@ -1,0 +1,619 @@
+// capi.hip -- implementation of include/shader_ray_hip.h: scene upload,
+// validation and repacking, environment upload, render entry points.
+// Host code only; the kernels live in kernel_*.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "frame_params_defaults.h"
+#include "launch.h"
+#include "packed_layout.h"
+#include "shader_ray_hip.h"
+
+using namespace shray;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? SHRAY_ERR_OUT_OF_MEMORY : SHRAY_ERR_DEVICE, \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+    } while (0)
+
+const float kTerminatorF = 16777215.0f;   // raytracer.es.fs:384
+
+// binary32 -> binary16 bits, round to nearest even (GL_RGB16F upload, ray.cpp:474)
+uint16_t float_to_half_bits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    uint32_t mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u)
+        return sign | 0x7e00u;                      // NaN
+    if (mag >= 0x477ff000u)
+        return sign | 0x7c00u;                      // overflow -> inf (also inf itself)
+    if (mag < 0x33000001u)
+        return sign;                                // rounds to zero (<= 2^-25)
+    if (mag < 0x38800000u) {                        // subnormal half
+        const int shift = 126 - (int)(mag >> 23);   // 14..24
+        const uint32_t mant = (mag & 0x7fffffu) | 0x800000u;
+        const uint32_t q = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u);
+        const uint32_t halfway = 1u << (shift - 1);
+        const uint32_t up = (rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u;
+        return sign | (uint16_t)(q + up);
+    }
+    const uint32_t lsb = (mag >> 13) & 1u;
+    mag += 0xfffu + lsb;
+    return sign | (uint16_t)((mag - 0x38000000u) >> 13);
+}
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    ~DeviceBuffer() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+    }
+    hipError_t upload(const void *src, size_t bytes)
+    {
+        release();
+        if (bytes == 0)
+            bytes = 16;   // keep a valid pointer for empty scenes
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            return e;
+        if (src)
+            return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+        return hipMemset(p, 0, bytes);
+    }
+};
+
+}   // namespace
+
+struct shray_scene {
+    int device = 0;
+    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel
+    bool packed_ok = false;     // link tables verified against the packed tree
+    int stack_levels = 1;
+
+    DeviceBuffer positions, normals16, normals32, boxmin, boxmax, hitmiss, objects;
+    DeviceBuffer packed_nodes, packed_tris;
+    DeviceBuffer env;
+    DeviceBuffer counters;
+
+    SceneView view{};
+};
+
+namespace {
+
+// Validation + reconstruction of the tree from the eight (hit, miss) tables.
+// On success fills `nodes` (packed, depth-first) and the depth.
+struct TreeBuilder {
+    const shray_scene_desc &d;
+    uint32_t n, stride, tri_count;
+    std::vector<int32_t> neg, pos;      // per reference node; -1 for leaves
+    std::vector<uint8_t> axis;
+    std::string why;
+
+    explicit TreeBuilder(const shray_scene_desc &desc)
+        : d(desc), n((uint32_t)desc.group_count), stride(desc.data_texture_width * (uint32_t)desc.group_data_rows),
+          tri_count(desc.vertex_count / 3)
+    {
+    }
+
+    const float *link(int code, uint32_t node) const { return d.group_hitmiss + 2 * ((size_t)stride * code + node); }
+
+    // every link is END or a node index; every leaf names existing triangles
+    bool links_are_safe()
+    {
+        for (int code = 0; code < 8; code++) {
+            for (uint32_t g = 0; g < n; g++) {
+                for (int k = 0; k < 2; k++) {
+                    const float v = link(code, g)[k];
+                    if (v >= kTerminatorF)
+                        continue;
+                    if (!(v >= 0.0f) || v != floorf(v) || v >= (float)n) {
+                        why = "a hit/miss link is neither a node index nor a terminator";
+                        return false;
+                    }
+                }
+                const bool leaf = link(code, g)[0] == link(code, g)[1];
+                if (leaf) {
+                    const float s = d.group_objects[2 * (size_t)g], c = d.group_objects[2 * (size_t)g + 1];
+                    if (!(s >= 0.0f) || !(c >= 0.0f) || s != floorf(s) || c != floorf(c) ||
+                        (double)s + (double)c > (double)tri_count) {
+                        why = "a leaf's (start, count) does not name existing triangles";
+                        return false;
+                    }
+                }
+            }
+        }
+        return true;
+    }
+
+    // children + split axis of every branch, from the hit links alone
+    bool recover_children()
+    {
+        neg.assign(n, -1);
+        pos.assign(n, -1);
+        axis.assign(n, 0);
+        for (uint32_t g = 0; g < n; g++) {
+            const float h0 = link(0, g)[0];
+            bool leaf = h0 == link(0, g)[1];
+            for (int code = 1; code < 8; code++)
+                if ((link(code, g)[0] == link(code, g)[1]) != leaf)
+                    return false;
+            if (leaf)
+                continue;
+            // code 0 (all components <= 0) goes to the positive child first, code 7 to the negative
+            const float p = h0, m = link(7, g)[0];
+            if (p >= kTerminatorF || m >= kTerminatorF || p == m)
+                return false;
+            int found = -1;
+            for (int k = 0; k < 3 && found < 0; k++) {
+                bool ok = true;
+                for (int code = 0; code < 8 && ok; code++)
+                    ok = link(code, g)[0] == (((code >> k) & 1) ? m : p);
+                if (ok)
+                    found = k;
+            }
+            if (found < 0)
+                return false;
+            axis[g] = (uint8_t)found;
+            neg[g] = (int32_t)m;
+            pos[g] = (int32_t)p;
+        }
+        return true;
+    }
+
+    // Re-threads the recovered tree for each direction code and compares with
+    // the tables given; also checks it is a tree that reaches all n nodes.
+    bool tables_match(int *depth_out)
+    {
+        std::vector<uint32_t> stack;
+        int depth = 0;
+        for (int code = 0; code < 8; code++) {
+            uint32_t visited = 0;
+            stack.clear();
+            int64_t g = d.tree_root;
+            while (g >= 0) {
+                if (++visited > n)
+                    return false;   // a cycle
+                const int64_t next_subtree = stack.empty() ? -1 : (int64_t)stack.back();
+                const float expect_miss = next_subtree < 0 ? -1.0f : (float)next_subtree;
+                const float got_hit = link(code, (uint32_t)g)[0], got_miss = link(code, (uint32_t)g)[1];
+                auto same = [](float got, float expect) { return expect < 0 ? got >= kTerminatorF : got == expect; };
+                int64_t go;
+                if (neg[g] < 0) {
+                    if (!same(got_hit, expect_miss) || !same(got_miss, expect_miss))
+                        return false;
+                    go = next_subtree;
+                    if (!stack.empty())
+                        stack.pop_back();
+                } else {
+                    const bool neg_first = (code >> axis[g]) & 1;
+                    const int32_t near_child = neg_first ? neg[g] : pos[g];
+                    const int32_t far_child = neg_first ? pos[g] : neg[g];
+                    if (got_hit != (float)near_child || !same(got_miss, expect_miss))
+                        return false;
+                    stack.push_back((uint32_t)far_child);
+                    depth = std::max(depth, (int)stack.size());
+                    if (stack.size() > 64)
+                        return false;   // hitmiss_max_stack_size, world.cpp:228
+                    go = near_child;
+                }
+                g = go;
+            }
+            if (visited != n)
+                return false;
+        }
+        *depth_out = depth;
+        return true;
+    }
+
+    // depth-first (negative subtree first) packing
+    void pack(std::vector<PackedNode> &nodes, uint32_t *packed_root)
+    {
+        std::vector<uint32_t> new_index(n, 0);
+        std::vector<uint32_t> order;
+        order.reserve(n);
+        std::vector<uint32_t> todo(1, (uint32_t)d.tree_root);
+        while (!todo.empty()) {
+            const uint32_t g = todo.back();
+            todo.pop_back();
+            new_index[g] = (uint32_t)order.size();
+            order.push_back(g);
+            if (neg[g] >= 0) {
+                todo.push_back((uint32_t)pos[g]);
+                todo.push_back((uint32_t)neg[g]);
+            }
+        }
+        nodes.resize(n);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t g = order[k];
+            PackedNode &pn = nodes[k];
+            memcpy(pn.lo, d.group_boxmin + 3 * (size_t)g, 12);
+            memcpy(pn.hi, d.group_boxmax + 3 * (size_t)g, 12);
+            if (neg[g] >= 0) {
+                pn.a = ((uint32_t)axis[g] << 30) | new_index[pos[g]];
+                pn.b = new_index[neg[g]];
+            } else {
+                pn.a = (uint32_t)d.group_objects[2 * (size_t)g];
+                pn.b = kLeafFlag | (uint32_t)d.group_objects[2 * (size_t)g + 1];
+            }
+        }
+        *packed_root = new_index[(uint32_t)d.tree_root];
+    }
+};
+
+int validate_params(const shray_frame_params *p, int width, int height, int spp)
+{
+    if (!p)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "frame params are NULL");
+    if (p->struct_size != sizeof(shray_frame_params))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_frame_params.struct_size is %u, this library expects %zu",
+                    p->struct_size, sizeof(shray_frame_params));
+    if (width <= 0 || height <= 0 || spp <= 0 || width > 65536 || height > 65536 || spp > (1 << 20))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad frame geometry %dx%d, %d spp", width, height, spp);
+    if (p->which != 0)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT,
+                    "which = %d: only the normal rendering mode (0) is implemented; the reference's debug views "
+                    "(1, 2, 3, 5) are not", p->which);
+    if (p->bounce_count < 0 || p->bounce_count > 64 || p->max_bvh_iterations < 1 || p->max_bvh_iterations > (1 << 24) ||
+        p->max_leaf_tests < 0 || p->max_leaf_tests > (1 << 24))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shader constants out of range (bounce_count %d, max_bvh_iterations %d, "
+                    "max_leaf_tests %d)", p->bounce_count, p->max_bvh_iterations, p->max_leaf_tests);
+    return SHRAY_OK;
+}
+
+int make_frame_view(const shray_frame_params *p, int width, int height, int spp, const shray_tile_set *tiles,
+                    FrameView *fr)
+{
+    memset(fr, 0, sizeof(*fr));
+    memcpy(fr->camera_matrix, p->camera_matrix, 64);
+    memcpy(fr->camera_normal_matrix, p->camera_normal_matrix, 64);
+    memcpy(fr->object_matrix, p->object_matrix, 64);
+    memcpy(fr->object_normal_matrix, p->object_normal_matrix, 64);
+    memcpy(fr->object_normal_inverse, p->object_normal_inverse, 64);
+    fr->image_plane_width = p->image_plane_width;
+    fr->aspect = p->aspect;
+    memcpy(fr->light_dir, p->light_dir, 12);
+    memcpy(fr->specular_color, p->specular_color, 12);
+    memcpy(fr->diffuse_color, p->diffuse_color, 12);
+    fr->bounce_count = p->bounce_count;
+    fr->max_bvh_iterations = p->max_bvh_iterations;
+    fr->max_leaf_tests = p->max_leaf_tests;
+    fr->cast_shadows = p->cast_shadows;
+    fr->tonemap = p->tonemap;
+    fr->normals_fp16 = p->normals_fp16;
+    fr->width = width;
+    fr->height = height;
+    fr->spp = spp;
+
+    const bool tiled = tiles && tiles->tile_stride > 0;
+    if (!tiled) {
+        fr->tile_stride = 0;
+        fr->patches_x = (width + 15) / 16;
+        fr->patches_per_unit = fr->patches_x * ((height + 15) / 16);
+        fr->total_patches = (uint32_t)fr->patches_per_unit;
+        return SHRAY_OK;
+    }
+    if (tiles->tile_w <= 0 || tiles->tile_h <= 0 || tiles->tile_w % 16 || tiles->tile_h % 16 ||
+        tiles->tile_phase < 0 || tiles->tile_phase >= tiles->tile_stride)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "tile set {%d x %d, stride %d, phase %d}: tile sizes must be positive "
+                    "multiples of 16 and 0 <= phase < stride", tiles->tile_w, tiles->tile_h, tiles->tile_stride,
+                    tiles->tile_phase);
+    fr->tile_w = tiles->tile_w;
+    fr->tile_h = tiles->tile_h;
+    fr->tile_stride = tiles->tile_stride;
+    fr->tile_phase = tiles->tile_phase;
+    fr->tiles_x = (width + tiles->tile_w - 1) / tiles->tile_w;
+    const int tiles_y = (height + tiles->tile_h - 1) / tiles->tile_h;
+    const int64_t total_tiles = (int64_t)fr->tiles_x * tiles_y;
+    fr->owned_tiles = (int32_t)((total_tiles - tiles->tile_phase + tiles->tile_stride - 1) / tiles->tile_stride);
+    if (fr->owned_tiles < 0)
+        fr->owned_tiles = 0;
+    fr->patches_x = tiles->tile_w / 16;
+    fr->patches_per_unit = fr->patches_x * (tiles->tile_h / 16);
+    fr->total_patches = (uint32_t)fr->owned_tiles * (uint32_t)fr->patches_per_unit;
+    return SHRAY_OK;
+}
+
+int launch(shray_scene *s, const FrameView &fr, float4 *d_out, DeviceCounters *d_counters, hipStream_t stream)
+{
+    if (fr.total_patches == 0)
+        return SHRAY_OK;
+    hipError_t e;
+    if (s->kernel_id == 0 && s->packed_ok)
+        e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
+    else
+        e = launch_threaded(s->view, fr, d_out, d_counters, stream);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return SHRAY_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int shray_abi_version(void) { return SHRAY_ABI_VERSION; }
+
+const char *shray_last_error(void) { return g_error.c_str(); }
+
+int shray_device_count(int *count)
+{
+    if (!count)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(SHRAY_ERR_NO_DEVICE, "no HIP device is visible");
+    }
+    *count = n;
+    return SHRAY_OK;
+}
+
+int shray_set_device(int device_index)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SHRAY_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device_index < 0 || device_index >= n)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device_index, n);
+    HIP_TRY(hipSetDevice(device_index));
+    return SHRAY_OK;
+}
+
+void shray_frame_params_init(shray_frame_params *params)
+{
+    if (params)
+        shray_frame_params_defaults(params);
+}
+
+int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
+{
+    if (!desc || !out_scene)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "desc or out_scene is NULL");
+    *out_scene = nullptr;
+    if (desc->struct_size != sizeof(shray_scene_desc))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_scene_desc.struct_size is %u, this library expects %zu",
+                    desc->struct_size, sizeof(shray_scene_desc));
+    if (desc->data_texture_width == 0 || desc->group_count < 1 || desc->group_data_rows < 1 ||
+        desc->tree_root < 0 || desc->tree_root >= desc->group_count || desc->vertex_count % 3 != 0)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "inconsistent counts (width %u, %d nodes in %d rows, root %d, %u vertices)",
+                    desc->data_texture_width, desc->group_count, desc->group_data_rows, desc->tree_root,
+                    desc->vertex_count);
+    const uint64_t stride = (uint64_t)desc->data_texture_width * (uint64_t)desc->group_data_rows;
+    const uint64_t vertex_texels = (uint64_t)desc->data_texture_width * (uint64_t)desc->vertex_data_rows;
+    if ((uint64_t)desc->group_count > stride || desc->vertex_count > vertex_texels)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "counts exceed width * rows");
+    if (!desc->group_boxmin || !desc->group_boxmax || !desc->group_hitmiss || !desc->group_objects ||
+        (desc->vertex_count && (!desc->vertex_positions || !desc->vertex_normals)))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "a required array is NULL");
+    // The shader carries every index as float32 (raytracer.es.fs:239-245, :384):
+    // exact only below 2^24, and node links at or above 16777215 mean "stop".
+    if (stride * 8 > 16777216ull || desc->vertex_count > 16777216u)
+        return fail(SHRAY_ERR_INDEX_RANGE, "scene too large for float32 indices (%llu link texels, %u vertices; "
+                    "limit 2^24)", (unsigned long long)(stride * 8), desc->vertex_count);
+
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return fail(SHRAY_ERR_NO_DEVICE, "no HIP device is available (hipGetDevice failed)");
+
+    TreeBuilder tb(*desc);
+    if (!tb.links_are_safe())
+        return fail(SHRAY_ERR_BAD_TREE, "%s", tb.why.c_str());
+
+    std::unique_ptr<shray_scene> s(new shray_scene);
+    s->device = device;
+    const size_t nv = desc->vertex_count, ng = (size_t)desc->group_count;
+
+    HIP_TRY(s->positions.upload(desc->vertex_positions, nv * 12));
+    HIP_TRY(s->normals32.upload(desc->vertex_normals, nv * 12));
+    {
+        std::vector<uint16_t> halves(nv * 3);
+        for (size_t k = 0; k < halves.size(); k++)
+            halves[k] = float_to_half_bits(desc->vertex_normals[k]);
+        HIP_TRY(s->normals16.upload(halves.data(), halves.size() * 2));
+    }
+    HIP_TRY(s->boxmin.upload(desc->group_boxmin, ng * 12));
+    HIP_TRY(s->boxmax.upload(desc->group_boxmax, ng * 12));
+    HIP_TRY(s->objects.upload(desc->group_objects, ng * 8));
+    HIP_TRY(s->hitmiss.upload(desc->group_hitmiss, (size_t)stride * 8 * 8));
+    HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters)));
+
+    // packed layout for the stack kernel, if the tables describe a canonical threaded tree
+    int depth = 0;
+    if (tb.recover_children() && tb.tables_match(&depth)) {
+        std::vector<PackedNode> nodes;
+        uint32_t packed_root = 0;
+        tb.pack(nodes, &packed_root);
+        const size_t nt = nv / 3;
+        std::vector<PackedTri> tris(nt);
+        for (size_t t = 0; t < nt; t++) {
+            const float *v = desc->vertex_positions + 9 * t;
+            PackedTri &pt = tris[t];
+            memset(&pt, 0, sizeof(pt));
+            for (int a = 0; a < 3; a++) {
+                pt.v0[a] = v[a];
+                pt.e0[a] = v[3 + a] - v[a];        // e0 = v1 - v0, raytracer.es.fs:304
+                pt.e1[a] = v[a] - v[6 + a];        // e1 = v0 - v2, raytracer.es.fs:305
+            }
+        }
+        HIP_TRY(s->packed_nodes.upload(nodes.data(), nodes.size() * sizeof(PackedNode)));
+        HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
+        s->view.packed_root = packed_root;
+        s->stack_levels = std::max(1, depth);
+        s->packed_ok = true;
+    }
+
+    SceneView &v = s->view;
+    v.positions = (const float *)s->positions.p;
+    v.normals16 = (const uint16_t *)s->normals16.p;
+    v.normals32 = (const float *)s->normals32.p;
+    v.boxmin = (const float *)s->boxmin.p;
+    v.boxmax = (const float *)s->boxmax.p;
+    v.hitmiss = (const float *)s->hitmiss.p;
+    v.objects = (const float *)s->objects.p;
+    v.table_stride = (uint32_t)stride;
+    v.group_count = (uint32_t)ng;
+    v.triangle_count = (uint32_t)(nv / 3);
+    v.tree_root = (float)desc->tree_root;
+    v.packed_nodes = s->packed_nodes.p;
+    v.packed_tris = s->packed_tris.p;
+    v.env = nullptr;
+    v.env_w = v.env_h = 0;
+
+    *out_scene = s.release();
+    return SHRAY_OK;
+}
+
+int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height)
+{
+    if (!scene || !rgb || width <= 0 || height <= 0 || width > 32768 || height > 32768)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad environment (%p, %d x %d)", (const void *)rgb, width, height);
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(scene->env.upload(rgb, (size_t)width * height * 12));
+    scene->view.env = (const float *)scene->env.p;
+    scene->view.env_w = width;
+    scene->view.env_h = height;
+    return SHRAY_OK;
+}
+
+int shray_scene_destroy(shray_scene *scene)
+{
+    if (!scene)
+        return SHRAY_OK;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+    return SHRAY_OK;
+}
+
+int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
+{
+    if (!scene || kernel_id < 0 || kernel_id > 1)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded)", kernel_id);
+    if (kernel_id == 0 && !scene->packed_ok)
+        return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
+                    "literal threaded kernel (1) can run it");
+    scene->kernel_id = kernel_id;
+    return SHRAY_OK;
+}
+
+int64_t shray_tile_buffer_bytes(int width, int height, const shray_tile_set *tiles)
+{
+    if (width <= 0 || height <= 0)
+        return 0;
+    if (!tiles || tiles->tile_stride <= 0)
+        return (int64_t)width * height * 16;
+    if (tiles->tile_w <= 0 || tiles->tile_h <= 0 || tiles->tile_phase < 0 || tiles->tile_phase >= tiles->tile_stride)
+        return 0;
+    const int64_t tx = (width + tiles->tile_w - 1) / tiles->tile_w, ty = (height + tiles->tile_h - 1) / tiles->tile_h;
+    const int64_t owned = (tx * ty - tiles->tile_phase + tiles->tile_stride - 1) / tiles->tile_stride;
+    return std::max<int64_t>(owned, 0) * tiles->tile_w * tiles->tile_h * 16;
+}
+
+int shray_render_device(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                        const shray_tile_set *tiles, void *d_rgba_out, void *hip_stream)
+{
+    if (!scene || !d_rgba_out)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or output buffer is NULL");
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    if (!scene->view.env)
+        return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");
+    FrameView fr;
+    rc = make_frame_view(params, width, height, spp, tiles, &fr);
+    if (rc)
+        return rc;
+    return launch(scene, fr, (float4 *)d_rgba_out, nullptr, (hipStream_t)hip_stream);
+}
+
+int shray_render(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                 float *rgba_out_host)
+{
+    if (!scene || !rgba_out_host)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or output buffer is NULL");
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    DeviceBuffer frame;
+    const size_t bytes = (size_t)width * height * 16;
+    HIP_TRY(frame.upload(nullptr, bytes));
+    rc = shray_render_device(scene, params, width, height, spp, nullptr, frame.p, nullptr);
+    if (rc)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgba_out_host, frame.p, bytes, hipMemcpyDeviceToHost));
+    return SHRAY_OK;
+}
+
+int shray_render_counters(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                          float *rgba_out_host, shray_counters *counters)
+{
+    if (!scene || !counters)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or counters is NULL");
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    if (!scene->view.env)
+        return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");
+    HIP_TRY(hipSetDevice(scene->device));
+    FrameView fr;
+    rc = make_frame_view(params, width, height, spp, nullptr, &fr);
+    if (rc)
+        return rc;
+    DeviceBuffer frame;
+    const size_t bytes = (size_t)width * height * 16;
+    HIP_TRY(frame.upload(nullptr, bytes));
+    HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(DeviceCounters)));
+    rc = launch(scene, fr, (float4 *)frame.p, (DeviceCounters *)scene->counters.p, nullptr);
+    if (rc)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    DeviceCounters dc;
+    HIP_TRY(hipMemcpy(&dc, scene->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    if (rgba_out_host)
+        HIP_TRY(hipMemcpy(rgba_out_host, frame.p, bytes, hipMemcpyDeviceToHost));
+    counters->node_visits = dc.node_visits;
+    counters->leaf_visits = dc.leaf_visits;
+    counters->triangle_tests = dc.triangle_tests;
+    counters->shaded_hits = dc.shaded_hits;
+    counters->env_lookups = dc.env_lookups;
+    counters->traversals = dc.traversals;
+    counters->bad_hits = dc.bad_hits;
+    counters->samples = (uint64_t)width * height * spp;
+    return SHRAY_OK;
+}
+
+}   // extern "C"

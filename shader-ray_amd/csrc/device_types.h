@@ -1,0 +1,72 @@
+// device_types.h -- plain structs passed by value to the gfx950 kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace shray {
+
+// Scene arrays resident in HBM.
+//
+// "Reference layout" (what shray_scene_create receives, mirrored 1:1; used by
+// the literal threaded kernel):
+//   positions   3 x f32 per vertex, 3 vertices per triangle      (RGB32F, ray.cpp:471)
+//   normals16   3 x f16 per vertex                               (RGB16F, ray.cpp:474)
+//   normals32   3 x f32 per vertex (only read when normals_fp16 == 0)
+//   boxmin/max  3 x f32 per node                                 (RGB32F, ray.cpp:492-497)
+//   hitmiss     8 tables x table_stride x (hit, miss) f32        (RG32F, ray.cpp:484)
+//   objects     (start, count) f32 per node                      (RG32F, ray.cpp:480)
+//
+// "Packed layout" (built once at scene_create, used by the stack kernel; see
+// DESIGN.md "Data layout in HBM"):
+//   nodes       32 B per node, depth-first order, near/far resolved per ray
+//   tris        48 B per triangle: v0, e0 = v1 - v0, e1 = v0 - v2 (+ original index)
+struct SceneView {
+    const float *positions;
+    const uint16_t *normals16;
+    const float *normals32;
+    const float *boxmin;
+    const float *boxmax;
+    const float *hitmiss;
+    const float *objects;
+    uint32_t table_stride;   // data_texture_width * group_data_rows
+    uint32_t group_count;
+    uint32_t triangle_count;
+    float tree_root;
+
+    const void *packed_nodes;   // PackedNode[group_count]
+    const void *packed_tris;    // PackedTri[triangle_count]
+    uint32_t packed_root;
+
+    const float *env;   // RGB f32, row 0 = t = 0 (straight down)
+    int32_t env_w, env_h;
+};
+
+// Per-launch parameters: the frame block plus frame geometry and tiling.
+struct FrameView {
+    float camera_matrix[16];
+    float camera_normal_matrix[16];
+    float object_matrix[16];
+    float object_normal_matrix[16];
+    float object_normal_inverse[16];
+    float image_plane_width, aspect;
+    float light_dir[3];
+    float specular_color[3];
+    float diffuse_color[3];
+    int32_t bounce_count, max_bvh_iterations, max_leaf_tests;
+    int32_t cast_shadows, tonemap, normals_fp16;
+
+    int32_t width, height, spp;
+    // tiling: tile_stride == 0 means "whole frame, row-major output"
+    int32_t tile_w, tile_h, tile_stride, tile_phase;
+    int32_t tiles_x;          // tiles per frame row
+    int32_t owned_tiles;      // tiles this launch renders
+    int32_t patches_x;        // 16x16 patches per row (of the frame, or of one tile)
+    int32_t patches_per_unit; // patches per frame / per tile
+    uint32_t total_patches;   // grid size in patches
+};
+
+struct DeviceCounters {
+    unsigned long long node_visits, leaf_visits, triangle_tests, shaded_hits, env_lookups, traversals, bad_hits, samples;
+};
+
+}   // namespace shray

@@ -1,0 +1,35 @@
+// kernel_stack.hip -- kernel id 0: per-ray LDS stack over the packed BVH (stack_traversal.h).
+//
+// LDS: BLOCK * stack_levels * 4 bytes of dynamic shared memory; stack_levels
+// is the tree's depth (computed at scene creation), so the bunny-class tree
+// (depth 20) costs 20 KB per 256-thread workgroup and leaves room for 8
+// workgroups (32 waves) per CU.
+#include "launch.h"
+#include "stack_traversal.h"
+
+namespace shray {
+
+constexpr int kBlock = 256;
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock> trav;
+    trav.stack = lds_stack + threadIdx.x;
+    trace_pixels<StackTraversal<kBlock>, COUNT>(sc, fr, out, counters, trav);
+}
+
+hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
+                        hipStream_t stream, int stack_levels)
+{
+    const dim3 grid(fr.total_patches), block(kBlock);
+    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t);
+    if (counters)
+        hipLaunchKernelGGL(trace_stack_kernel<true>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+    else
+        hipLaunchKernelGGL(trace_stack_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+    return hipGetLastError();
+}
+
+}   // namespace shray

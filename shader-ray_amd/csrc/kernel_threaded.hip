@@ -1,0 +1,25 @@
+// kernel_threaded.hip -- kernel id 1: literal threaded traversal (threaded_traversal.h).
+#include "launch.h"
+#include "threaded_traversal.h"
+
+namespace shray {
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) trace_threaded_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
+{
+    ThreadedTraversal trav;
+    trace_pixels<ThreadedTraversal, COUNT>(sc, fr, out, counters, trav);
+}
+
+hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
+                           hipStream_t stream)
+{
+    const dim3 grid(fr.total_patches), block(256);
+    if (counters)
+        hipLaunchKernelGGL(trace_threaded_kernel<true>, grid, block, 0, stream, sc, fr, out, counters);
+    else
+        hipLaunchKernelGGL(trace_threaded_kernel<false>, grid, block, 0, stream, sc, fr, out, counters);
+    return hipGetLastError();
+}
+
+}   // namespace shray

@@ -1,0 +1,17 @@
+// launch.h -- host-side launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace shray {
+
+// counters == nullptr selects the plain (timed) kernel, otherwise the counting variant.
+hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
+                           hipStream_t stream);
+// stack_levels = capacity of the per-ray stack (the tree's depth)
+hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
+                        hipStream_t stream, int stack_levels);
+
+}   // namespace shray

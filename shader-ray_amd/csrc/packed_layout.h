@@ -1,0 +1,49 @@
+// packed_layout.h -- the MI355X-side BVH layout, built once per scene.
+//
+// The reference keeps boxes, links and leaf ranges in five float textures and
+// threads the tree eight times (world.cpp:231-288).  For the GPU the same tree
+// is repacked so that one node visit is two 16-byte loads and one triangle
+// test is three, and the eight link tables collapse into "push the far child":
+//
+//   PackedNode (32 B, depth-first order, negative subtree first)
+//     lo = { boxmin.xyz, a }      hi = { boxmax.xyz, b }
+//     branch: a = (split_axis << 30) | positive_child      b = negative_child
+//     leaf  : a = first triangle                            b = 0x80000000 | count
+//   PackedTri (48 B, same triangle order as the reference arrays)
+//     { v0.xyz, e0.x } { e0.yz, e1.xy } { e1.z, 0, 0, 0 }   e0 = v1 - v0, e1 = v0 - v2
+//
+// e0 / e1 are the same single fp32 subtractions triangle_intersect performs
+// per test (raytracer.es.fs:304-305), hoisted to scene-creation time.
+// Visit order: a ray whose direction component along the split axis is > 0
+// descends into the negative child first, otherwise into the positive child
+// (world.cpp:259-265 with get_coded_dir, :214-220); the far child is pushed on
+// the ray's stack; "miss" = pop.  That reproduces the reference's eight
+// threaded orders exactly, which shray_scene_create verifies table by table
+// before it lets the stack kernel run.
+#pragma once
+
+#include <stdint.h>
+
+namespace shray {
+
+struct PackedNode {
+    float lo[3];
+    uint32_t a;
+    float hi[3];
+    uint32_t b;
+};
+static_assert(sizeof(PackedNode) == 32, "PackedNode must be 32 bytes");
+
+struct PackedTri {
+    float v0[3];
+    float e0[3];
+    float e1[3];
+    float pad[3];
+};
+static_assert(sizeof(PackedTri) == 48, "PackedTri must be 48 bytes");
+
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kChildMask = 0x3fffffffu;
+constexpr uint32_t kNoNode = 0xffffffffu;
+
+}   // namespace shray

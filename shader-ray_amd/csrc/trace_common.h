@@ -1,0 +1,263 @@
+// trace_common.h -- device-side per-pixel path shared by the gfx950 kernels:
+// primary-ray generation, the bounce loop, shading, shadow rays, environment
+// lookup and tone mapping.  The BVH traversal itself is a policy class
+// (threaded_traversal.h / stack_traversal.h) plugged into trace_pixels<>.
+//
+// Restates, as one HIP kernel, the reference's two GLSL stages:
+//   raytracer.vs:39-60      primary ray through the image plane
+//   raytracer.es.fs:552-582 trace(): <= bounce_count closest-hit traversals,
+//                           Fresnel-weighted mirror bounces, shadow rays for
+//                           non-metals, one environment lookup at the end
+//   raytracer.es.fs:527-548 filmic tone map
+// Arithmetic contract (identical to the CPU oracle's; DESIGN.md "Arithmetic"):
+// single-rounded IEEE fp32 operations in the shader's order, compiled with
+// -ffp-contract=off and correctly rounded divide/sqrt; only atan2f / acosf /
+// powf are library calls.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace shray {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b)
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 unit(V3 a) { return a / sqrtf(dot3(a, a)); }
+// GLSL max/min: the SECOND operand wins only on a strict compare
+__device__ __forceinline__ float sel_max(float x, float y) { return x < y ? y : x; }
+__device__ __forceinline__ float sel_min(float x, float y) { return y < x ? y : x; }
+
+// column-major mat4 times (v, w)
+__device__ __forceinline__ V3 xform(const float *m, V3 v, float w)
+{
+    return mk(m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * w,
+              m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * w,
+              m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * w);
+}
+
+struct Hit {        // surface_hit, raytracer.es.fs:108-113
+    float t;
+    float which;    // triangle index as a float; -1 = none
+    float bu, bv;   // barycentric u, v (uvw = (1-u-v, u, v)); for a bad hit the marker colour is implied
+};
+
+constexpr float kFar = 10000000.0f;        // infinitely_far, fs:115
+constexpr float kRangeMax = 100000000.0f;  // traversal range, fs:491
+constexpr float kPi = 3.14159265259f;      // fs:116
+constexpr float kTerminator = 16777215.0f; // fs:384
+
+struct RayCounters {
+    unsigned int node_visits, leaf_visits, triangle_tests, shaded_hits, env_lookups, traversals, bad_hits;
+};
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h)
+{
+    return (float)__builtin_bit_cast(_Float16, h);   // exact widening (v_cvt_f32_f16)
+}
+
+// triangle_interpolate_normal, fs:288-295 (vertex normals from the fp16 or fp32 copy)
+__device__ __forceinline__ V3 interpolated_normal(const SceneView &sc, bool fp16, float which, float bu, float bv)
+{
+    const unsigned int base = 9u * (unsigned int)which;
+    float n[9];
+    if (fp16) {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            n[k] = half_bits_to_float(sc.normals16[base + k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            n[k] = sc.normals32[base + k];
+    }
+    const float bw = 1.0f - bu - bv;
+    return mk(n[0], n[1], n[2]) * bw + mk(n[3], n[4], n[5]) * bu + mk(n[6], n[7], n[8]) * bv;
+}
+
+// sample_environment, fs:127-155 with which == 0: level-0 bilinear, REPEAT wrap
+__device__ __forceinline__ V3 environment(const SceneView &sc, V3 d)
+{
+    const float tau = 2 * kPi;
+    const float dy = sel_min(sel_max(d.y, -1.0f), 1.0f);
+    const float s = 1.0f + atan2f(-d.z, d.x) / tau;
+    const float t = 1.0f - acosf(dy) / kPi;
+    const float u = s * (float)sc.env_w - 0.5f;
+    const float v = t * (float)sc.env_h - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    int i0 = (int)fu % sc.env_w, j0 = (int)fv % sc.env_h;
+    int i1 = (int)(fu + 1.0f) % sc.env_w, j1 = (int)(fv + 1.0f) % sc.env_h;
+    i0 += i0 < 0 ? sc.env_w : 0;
+    i1 += i1 < 0 ? sc.env_w : 0;
+    j0 += j0 < 0 ? sc.env_h : 0;
+    j1 += j1 < 0 ? sc.env_h : 0;
+    const float *r0 = sc.env + 3 * (size_t)j0 * sc.env_w;
+    const float *r1 = sc.env + 3 * (size_t)j1 * sc.env_w;
+    const V3 t00 = mk(r0[3 * i0], r0[3 * i0 + 1], r0[3 * i0 + 2]);
+    const V3 t10 = mk(r0[3 * i1], r0[3 * i1 + 1], r0[3 * i1 + 2]);
+    const V3 t01 = mk(r1[3 * i0], r1[3 * i0 + 1], r1[3 * i0 + 2]);
+    const V3 t11 = mk(r1[3 * i1], r1[3 * i1 + 1], r1[3 * i1 + 2]);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return t00 * w00 + t10 * w10 + t01 * w01 + t11 * w11;
+}
+
+// filmic, fs:527-531
+__device__ __forceinline__ float filmic(float c)
+{
+    const float x = sel_max(0.0f, c - 0.004f);
+    return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
+}
+
+// trace(), fs:552-582, with intersect_and_shade (fs:484-522) and
+// approximate_diffuse (fs:447-472) inlined.  Traversal::closest() runs
+// group_intersect (fs:386-443) on an object-space ray.
+template <class Traversal, bool COUNT>
+__device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr, Traversal &trav, V3 P, V3 D,
+                                       RayCounters &rc)
+{
+    V3 accumulated = mk(0, 0, 0);
+    V3 modulation = mk(1, 1, 1);
+    const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);
+    const V3 spec = mk(fr.specular_color[0], fr.specular_color[1], fr.specular_color[2]);
+    const V3 diff = mk(fr.diffuse_color[0], fr.diffuse_color[1], fr.diffuse_color[2]);
+    const bool has_diffuse = diff.x > 0.0f && diff.y > 0.0f && diff.z > 0.0f;   // fs:570 (object_color is white)
+
+    for (int bounce = 0; bounce < fr.bounce_count; bounce++) {
+        Hit hit{kFar, -1.0f, 0.0f, 0.0f};
+        trav.template closest<COUNT>(sc, fr, xform(fr.object_matrix, P, 1.0f), xform(fr.object_normal_matrix, D, 0.0f),
+                                     hit, rc);
+        if (hit.t >= kFar)
+            break;
+        if (hit.t == -1.0f) {   // iteration cap hit: the marker colour, unmodulated, no environment (fs:566-568)
+            if (COUNT)
+                rc.bad_hits++;
+            return mk(1.0f, 0.0f, 0.0f);
+        }
+        if (COUNT)
+            rc.shaded_hits++;
+        const V3 object_normal = interpolated_normal(sc, fr.normals_fp16 != 0, hit.which, hit.bu, hit.bv);
+        V3 n = xform(fr.object_normal_inverse, object_normal, 0.0f);
+        if (dot3(n, D) > 0.0f)
+            n = n * -1.0f;
+
+        const V3 at = P + D * hit.t;                      // ray_transfer, fs:69
+        const V3 R = D - n * (2.0f * dot3(n, D));         // reflect(), fs:86
+        const V3 P2 = at + n * .0001f;                    // surface fudge, fs:87
+        const float fresnel = powf(dot3(D, R) * .5f + .5f, 5.0f);
+        const V3 object_specular = spec + (mk(1.0f, 1.0f, 1.0f) - spec) * fresnel;   // f_schlick_vr, fs:479-482
+
+        if (has_diffuse) {
+            const float lcos = sel_max(0.0f, dot3(n, light));
+            V3 irradiance = mk(0, 0, 0);
+            bool lit = true;
+            if (fr.cast_shadows) {
+                Hit shadow{kFar, -1.0f, 0.0f, 0.0f};
+                trav.template closest<COUNT>(sc, fr, xform(fr.object_matrix, P2, 1.0f),
+                                             xform(fr.object_normal_matrix, light, 0.0f), shadow, rc);
+                lit = shadow.t >= kFar;
+            }
+            if (lit)
+                irradiance = irradiance + mk(1.0f, 1.0f, 1.0f) * lcos;
+            accumulated = accumulated + modulation * diff * irradiance;
+        }
+        modulation = modulation * object_specular;
+        P = P2;
+        D = R;
+    }
+    if (COUNT)
+        rc.env_lookups++;
+    return accumulated + modulation * environment(sc, D);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
+{
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    return s;
+}
+
+// One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four
+// 8x8 wave tiles so that the 64 rays of a wave stay spatially coherent.
+template <class Traversal, bool COUNT>
+__device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
+                                             DeviceCounters *counters, Traversal &trav)
+{
+    const unsigned int patch = blockIdx.x;
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
+    const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
+
+    int px, py;
+    size_t out_index;
+    bool store = true;
+    if (fr.tile_stride == 0) {
+        px = (int)(patch % (unsigned int)fr.patches_x) * 16 + lx;
+        py = (int)(patch / (unsigned int)fr.patches_x) * 16 + ly;
+        out_index = (size_t)py * fr.width + px;
+        store = px < fr.width && py < fr.height;
+    } else {
+        const unsigned int k = patch / (unsigned int)fr.patches_per_unit;
+        const unsigned int q = patch % (unsigned int)fr.patches_per_unit;
+        const unsigned int tile = k * (unsigned int)fr.tile_stride + (unsigned int)fr.tile_phase;
+        const int tx = (int)(tile % (unsigned int)fr.tiles_x), ty = (int)(tile / (unsigned int)fr.tiles_x);
+        const int tlx = (int)(q % (unsigned int)fr.patches_x) * 16 + lx;
+        const int tly = (int)(q / (unsigned int)fr.patches_x) * 16 + ly;
+        px = tx * fr.tile_w + tlx;
+        py = ty * fr.tile_h + tly;
+        out_index = (size_t)k * fr.tile_w * fr.tile_h + (size_t)tly * fr.tile_w + tlx;
+    }
+    const bool inside = px < fr.width && py < fr.height;
+
+    RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
+    V3 result = mk(0, 0, 0);
+    if (inside) {
+        const float fw = (float)fr.width, fh = (float)fr.height, fn = (float)fr.spp;
+        V3 sum = mk(0, 0, 0);
+        for (int s = 0; s < fr.spp; s++) {
+            // sub-pixel pattern of the oracle (oracle/shader_oracle.cpp header): centred Hammersley
+            const float ox = ((float)s + 0.5f) / fn;
+            const float oy = (float)__brev((unsigned int)s) * 2.3283064365386963e-10f + 0.5f / fn;
+            const float u = ((float)px + ox) / fw;
+            const float v = ((float)py + oy) / fh;
+            // image_plane_ray + ray_transform, vs:39-60; normalize, fs:619
+            const V3 eye = unit(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f));
+            const V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
+            const V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
+            const V3 radiance = trace_ray<Traversal, COUNT>(sc, fr, trav, P, D, rc);
+            sum = (fr.spp == 1) ? radiance : sum + radiance;
+        }
+        result = (fr.spp == 1) ? sum : sum / fn;
+        if (fr.tonemap)
+            result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
+    }
+    if (store)
+        out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+
+    if (COUNT) {
+        const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
+                                      rc.env_lookups, rc.traversals, rc.bad_hits};
+        unsigned long long *dst = &counters->node_visits;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const unsigned long long s = wave_sum(vals[k]);
+            if (lane == 0 && s)
+                atomicAdd(dst + k, s);
+        }
+    }
+}
+
+}   // namespace shray

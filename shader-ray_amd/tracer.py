@@ -1,0 +1,87 @@
+"""Python face of the HIP layer (include/shader_ray_hip.h): upload a flattened scene and
+an environment, render frames.  Device memory and streams are plumbing (torch tensors
+/ the current torch stream when torch is used); every pixel is produced by the gfx950
+kernels behind the C ABI.  There is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+KERNEL_STACK = 0      # per-ray LDS stack over the packed BVH (default)
+KERNEL_THREADED = 1   # literal hit/miss-table traversal over the reference arrays
+
+
+class Scene:
+    """One scene resident on one GPU (replaces the reference's texture upload,
+    ray.cpp:470-510)."""
+
+    def __init__(self, desc: N.SceneDesc, environment: np.ndarray | None = None, device: int | None = None):
+        self._lib = N.load_hip()
+        if device is not None:
+            N.check(self._lib.shray_set_device(device))
+        handle = C.c_void_p()
+        N.check(self._lib.shray_scene_create(C.byref(desc), C.byref(handle)))
+        self._handle = handle
+        if environment is not None:
+            self.set_environment(environment)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.shray_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_environment(self, rgb: np.ndarray):
+        """`rgb` is [height, width, 3] float32, row 0 = straight down (texture t = 0)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        h, w, c = rgb.shape
+        assert c == 3
+        N.check(self._lib.shray_scene_set_environment(self._handle, rgb.ctypes.data_as(N.c_float_p), w, h))
+
+    def set_kernel(self, kernel_id: int):
+        N.check(self._lib.shray_scene_set_kernel(self._handle, kernel_id))
+
+    def render(self, params: N.FrameParams, width: int, height: int, spp: int = 1) -> np.ndarray:
+        """Blocking render to host memory: RGBA float32 [height, width, 4], row 0 = bottom."""
+        out = np.empty((height, width, 4), dtype=np.float32)
+        N.check(self._lib.shray_render(self._handle, C.byref(params), width, height, spp,
+                                       out.ctypes.data_as(N.c_float_p)))
+        return out
+
+    def render_counters(self, params: N.FrameParams, width: int, height: int, spp: int = 1, want_image: bool = True):
+        out = np.empty((height, width, 4), dtype=np.float32) if want_image else None
+        counters = N.Counters()
+        N.check(self._lib.shray_render_counters(
+            self._handle, C.byref(params), width, height, spp,
+            out.ctypes.data_as(N.c_float_p) if want_image else None, C.byref(counters)))
+        return out, counters.as_dict()
+
+    def render_into(self, params: N.FrameParams, width: int, height: int, spp: int, out_ptr: int,
+                    stream_ptr: int = 0, tiles: N.TileSet | None = None):
+        """Asynchronous render into device memory (`out_ptr`, e.g. tensor.data_ptr()) on a
+        HIP stream (`stream_ptr`, e.g. torch.cuda.current_stream().cuda_stream)."""
+        N.check(self._lib.shray_render_device(
+            self._handle, C.byref(params), width, height, spp,
+            C.byref(tiles) if tiles is not None else None, C.c_void_p(out_ptr), C.c_void_p(stream_ptr)))
+
+
+def tile_buffer_bytes(width: int, height: int, tiles: N.TileSet | None) -> int:
+    return int(N.load_hip().shray_tile_buffer_bytes(width, height, C.byref(tiles) if tiles is not None else None))
+
+
+def algorithmic_bytes(counters: dict, pixels: int, normals_fp16: bool = True, out_bytes: int = 16) -> int:
+    """Cache-less byte count of the reference's own fetches:
+    32 B per node visit (24 B box + 8 B links), +8 B per leaf visit (start, count),
+    36 B per triangle test (3 x 12 B), 18 B per shaded hit (3 fp16 normals; 36 B if
+    fp32), 48 B per environment lookup (4 texels x 12 B), 16 B per output pixel."""
+    c = counters
+    return (32 * c["node_visits"] + 8 * c["leaf_visits"] + 36 * c["triangle_tests"]
+            + (18 if normals_fp16 else 36) * c["shaded_hits"] + 48 * c["env_lookups"] + out_bytes * pixels)

@@ -1,0 +1,241 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI, on a real MI355X.
+
+Bar (BASELINE.json north_star): pixels within 1e-4 relative of the CPU evaluation of the
+shader.  Because every traversal decision is made with single-rounded IEEE fp32
+arithmetic on both sides, the tests also demand that the per-ray work counters (node
+visits, leaf visits, triangle tests, shaded hits, ...) are EXACTLY equal -- i.e. the
+kernel visits the same nodes and tests the same triangles as the reference's threaded
+traversal would -- and allow zero out-of-tolerance pixels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import assert_images_match, default_params, single_leaf_scene
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KERNELS = [0, 1]   # 0 = packed stack kernel (default), 1 = literal threaded kernel
+
+
+@pytest.fixture(scope="module")
+def env_sky(pkg):
+    return pkg.scenes.environment_hdr_sky(512)
+
+
+@pytest.fixture(scope="module")
+def bunny(pkg, gpu, env_sky):
+    world = pkg.World(helpers.bunny_trisrc())
+    desc = world.flatten()
+    scene = pkg.Scene(desc, env_sky, device=0)
+    yield world, desc, scene
+    scene.close()
+
+
+def check_against_oracle(oracle_mod, scene, desc, env, params, W, H, spp, what):
+    want, cpu = oracle_mod.render(desc, env, params, W, H, spp)
+    for kernel in KERNELS:
+        scene.set_kernel(kernel)
+        got, gpu_counters = scene.render_counters(params, W, H, spp)
+        plain = scene.render(params, W, H, spp)
+        assert_images_match(got, want, f"{what} kernel {kernel}")
+        assert np.array_equal(plain, got), f"{what} kernel {kernel}: plain and counting kernels differ"
+        assert gpu_counters == cpu, f"{what} kernel {kernel}: counters {gpu_counters} != oracle {cpu}"
+    scene.set_kernel(0)
+    return want
+
+
+@pytest.mark.parametrize("material", [0, 6])
+def test_golden_frames(pkg, gpu, material):
+    """Committed oracle frames of the committed scene file (tests/golden)."""
+    frames = np.load(os.path.join(GOLDEN, "lobed_528.oracle.npz"))
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(128), device=0)
+    name = "gold" if material == 0 else "plaster"
+    for kernel in KERNELS:
+        scene.set_kernel(kernel)
+        got, counters = scene.render_counters(world.frame_params(64, 64, material=material), 64, 64, 1)
+        assert_images_match(got, frames[name], f"golden {name} kernel {kernel}")
+        assert [counters[k] for k in sorted(counters)] == frames[name + "_counters"].tolist()
+    if material == 6:
+        got = scene.render(world.frame_params(64, 64, material=6), 64, 64, 4)
+        assert_images_match(got, frames["plaster_4spp"], "golden plaster 4spp")
+    scene.close()
+
+
+def test_config1_primary_rays_256(pkg, gpu, oracle_mod, bunny, env_sky):
+    """BASELINE config 1: bunny-class mesh, 256x256, 1 spp, primary rays only."""
+    world, desc, scene = bunny
+    params = world.frame_params(256, 256, material=0)
+    params.bounce_count = 1
+    check_against_oracle(oracle_mod, scene, desc, env_sky, params, 256, 256, 1, "config 1")
+
+
+@pytest.mark.parametrize("material,spp", [(0, 1), (6, 1), (6, 3), (5, 1)])
+def test_bunny_full_path(pkg, gpu, oracle_mod, bunny, env_sky, material, spp):
+    """3 bounces, Fresnel modulation, shadow rays (plaster), fp16 normals; 160x120."""
+    world, desc, scene = bunny
+    params = world.frame_params(160, 120, material=material)
+    check_against_oracle(oracle_mod, scene, desc, env_sky, params, 160, 120, spp, f"bunny material {material} spp {spp}")
+
+
+def test_rotated_view_and_fp32_normals(pkg, gpu, oracle_mod, bunny, env_sky):
+    world, desc, scene = bunny
+    view = world.default_view()
+    view.object_rotation[:] = [0.9, 0.26726124, 0.53452248, 0.80178373]
+    view.light_rotation[:] = [1.1, 0.0, 0.6, 0.8]
+    view.zoom = view.zoom * 0.6
+    params = world.frame_params(128, 96, view, material=6, diffuse=2)
+    params.normals_fp16 = 0
+    check_against_oracle(oracle_mod, scene, desc, env_sky, params, 128, 96, 1, "rotated, fp32 normals")
+    params.cast_shadows = 0
+    params.tonemap = 0
+    check_against_oracle(oracle_mod, scene, desc, env_sky, params, 128, 96, 1, "no shadows, no tonemap")
+
+
+def test_obj_scene_off_origin(pkg, gpu, oracle_mod, env_sky):
+    world = pkg.World(helpers.small_obj_no_normals())
+    desc = world.flatten()
+    scene = pkg.Scene(desc, pkg.scenes.environment_grid(256), device=0)
+    params = world.frame_params(96, 96, material=1)
+    check_against_oracle(oracle_mod, scene, desc, pkg.scenes.environment_grid(256), params, 96, 96, 1, "obj + grid env")
+    scene.close()
+
+
+def test_hand_built_edge_cases(pkg, gpu, oracle_mod):
+    import test_oracle_kat as kat
+    env = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    cases = {
+        "far triangle (env only)": (kat.far_away_triangle(), default_params(pkg, 40, 24)),
+        "mirror quad": (single_leaf_scene(kat.mirror_quad()), default_params(pkg, 40, 24, zoom=3.0)),
+        "plaster quad": (single_leaf_scene(kat.mirror_quad()), default_params(pkg, 40, 24, zoom=3.0, material=6)),
+        "iteration cap 401": (kat.chain_scene(401), default_params(pkg, 8, 8)),
+        "iteration cap 400": (kat.chain_scene(400), default_params(pkg, 8, 8)),
+    }
+    tris = [[[-5, -5, -float(k)], [5, -5, -float(k)], [0, 5, -float(k)]] for k in range(10)] + [[[-5, -5, 1.0], [5, -5, 1.0], [0, 5, 1.0]]]
+    cases["11-triangle leaf"] = (single_leaf_scene(tris), default_params(pkg, 16, 16))
+    cases["empty leaf"] = (single_leaf_scene([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], count=0), default_params(pkg, 16, 16))
+    for what, (hand, params) in cases.items():
+        scene = pkg.Scene(hand.desc, env, device=0)
+        W = int(round(1.0 / 1.0)) and None
+        w, h = (40, 24) if "quad" in what or "far" in what else ((8, 8) if "cap" in what else (16, 16))
+        want, cpu = oracle_mod.render(hand.desc, env, params, w, h, 1)
+        kernels = [1] if "cap" in what else KERNELS   # a chain of leaves is not a binary tree: threaded kernel only
+        for kernel in kernels:
+            scene.set_kernel(kernel)
+            got, counters = scene.render_counters(params, w, h, 1)
+            assert_images_match(got, want, f"{what} kernel {kernel}")
+            assert counters == cpu, (what, kernel, counters, cpu)
+        if "cap" in what:
+            with pytest.raises(pkg._native.ShrayError):
+                scene.set_kernel(0)     # refused: tables are not a canonical threaded tree
+            got = scene.render(params, w, h, 1)   # default selection falls back to the threaded kernel
+            assert_images_match(got, want, f"{what} default kernel")
+        scene.close()
+
+
+def test_empty_world_renders_environment(pkg, gpu, oracle_mod, tmp_path):
+    path = tmp_path / "empty.trisrc"
+    path.write_text("")
+    world = pkg.World(str(path))
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(64)
+    scene = pkg.Scene(desc, env, device=0)
+    params = default_params(pkg, 32, 32)
+    check_against_oracle(oracle_mod, scene, desc, env, params, 32, 32, 1, "empty world")
+    scene.close()
+
+
+def test_tile_sets_reassemble_to_the_full_frame(pkg, gpu, bunny):
+    """Interleaved tile ownership (the multi-GPU split) is bit-identical to one full render."""
+    import torch
+    from shader_ray_amd.multigpu import assemble_tiles
+    world, desc, scene = bunny
+    W, H = 200, 136           # not a multiple of the tile size: edge tiles are padded
+    params = world.frame_params(W, H, material=0)
+    full = scene.render(params, W, H, 1)
+    N = pkg._native
+    for (tw, th, stride) in ((32, 32, 3), (16, 48, 2), (64, 32, 8)):
+        parts = []
+        for phase in range(stride):
+            tiles = N.TileSet(tw, th, stride, phase)
+            nbytes = pkg.tracer.tile_buffer_bytes(W, H, tiles)
+            buf = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda:0")
+            scene.render_into(params, W, H, 1, buf.data_ptr(), torch.cuda.current_stream().cuda_stream, tiles)
+            torch.cuda.synchronize()
+            parts.append(buf.cpu().numpy())
+        frame = assemble_tiles(parts, W, H, tw, th)
+        assert np.array_equal(frame, full), (tw, th, stride)
+
+
+def test_full_size_properties_1080p(pkg, gpu, oracle_mod, bunny, env_sky):
+    """BASELINE config 2 size (1920x1080, gold): size-independent properties instead of a
+    full CPU render -- kernel 0 == kernel 1 bit for bit, run-to-run determinism, alpha = 1,
+    counters identical between kernels, and a band of rows checked against the oracle."""
+    world, desc, scene = bunny
+    W, H = 1920, 1080
+    params = world.frame_params(W, H, material=0)
+    scene.set_kernel(0)
+    a, ca = scene.render_counters(params, W, H, 1)
+    a2 = scene.render(params, W, H, 1)
+    scene.set_kernel(1)
+    b, cb = scene.render_counters(params, W, H, 1)
+    scene.set_kernel(0)
+    assert np.array_equal(a, a2) and np.array_equal(a, b) and ca == cb
+    assert np.all(a[..., 3] == 1.0) and not np.isnan(a).any()
+    assert ca["samples"] == W * H and ca["bad_hits"] == 0
+    rows = (520, 560)    # through the middle of the object
+    want, _ = oracle_mod.render(desc, env_sky, params, W, H, 1, rows=rows)
+    assert_images_match(a[rows[0]:rows[1]], want[rows[0]:rows[1]], "1080p rows 520..560")
+
+
+def test_million_triangle_scene(pkg, gpu, oracle_mod, env_sky):
+    """BASELINE config 4 scene (1M-triangle OBJ, deep BVH) on a reduced frame: parity
+    including the iteration-cap pixels (max_bvh_iterations = 400 is 'a little too few',
+    raytracer.es.fs:381)."""
+    world = pkg.World(helpers.million_obj())
+    assert world.triangle_count == 1_000_000
+    desc = world.flatten()
+    scene = pkg.Scene(desc, env_sky, device=0)
+    params = world.frame_params(192, 108, material=0)
+    check_against_oracle(oracle_mod, scene, desc, env_sky, params, 192, 108, 1, "1M triangles")
+    # a tighter cap makes the red marker appear: same pixels on both sides
+    params.max_bvh_iterations = 60
+    want = check_against_oracle(oracle_mod, scene, desc, env_sky, params, 192, 108, 1, "1M triangles, cap 60")
+    red = np.array([oracle_mod.filmic(1.0), 0.0, 0.0], np.float32)
+    assert (np.abs(want[..., :3] - red).max(axis=-1) < 1e-6).sum() > 0
+    scene.close()
+
+
+def test_error_paths(pkg, gpu, bunny, env_sky):
+    N = pkg._native
+    world, desc, scene = bunny
+    params = world.frame_params(32, 32)
+    fresh = pkg.Scene(desc, None, device=0)
+    with pytest.raises(N.ShrayError) as e:
+        fresh.render(params, 32, 32, 1)
+    assert e.value.code == -7          # SHRAY_ERR_NO_ENVIRONMENT
+    fresh.close()
+    bad = params.copy()
+    bad.which = 1
+    with pytest.raises(N.ShrayError) as e:
+        scene.render(bad, 32, 32, 1)
+    assert e.value.code == -1 and "which" in str(e.value)
+    bad = params.copy()
+    bad.struct_size = 12
+    with pytest.raises(N.ShrayError):
+        scene.render(bad, 32, 32, 1)
+    with pytest.raises(N.ShrayError):
+        scene.render(params, 0, 32, 1)
+    # a link that points outside the node array is rejected at creation, never traversed
+    hand = single_leaf_scene([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]])
+    hand.keep["hm"][3, 0, 0] = 7.0
+    with pytest.raises(N.ShrayError) as e:
+        pkg.Scene(hand.desc, env_sky, device=0)
+    assert e.value.code == -6          # SHRAY_ERR_BAD_TREE
+    hand = single_leaf_scene([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], count=5)   # names triangles that do not exist
+    with pytest.raises(N.ShrayError) as e:
+        pkg.Scene(hand.desc, env_sky, device=0)
+    assert e.value.code == -6

@@ -1,0 +1,117 @@
+"""Loader behaviour and error handling of the host layer, mirroring what the reference's
+loaders do with the same input (trisrc-support.cpp:43-105, obj-support.cpp:226-360,
+world.cpp:46-134)."""
+import numpy as np
+import pytest
+
+
+def write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+    return str(path)
+
+
+TRI = ('"*" t 0.5 0.5 0.5 1 20\n'
+       '0 0 0 0 0 1 1 1 1 1 0 0\n'
+       '1 0 0 0 0 1 1 1 1 1 0 0\n'
+       '0 1 0 0 0 2 1 1 1 1 0 0\n')
+
+
+def test_trisrc_single_triangle(pkg, tmp_path):
+    w = pkg.World(write(tmp_path / "one.trisrc", TRI))
+    a = w.arrays()
+    assert w.triangle_count == 1 and a["group_count"] == 1 and a["tree_root"] == 0
+    assert np.array_equal(a["vertex_positions"], np.array([0, 0, 0, 1, 0, 0, 0, 1, 0], np.float32))
+    assert np.array_equal(a["vertex_normals"].reshape(3, 3)[2], np.array([0, 0, 1], np.float32))   # normalised
+    assert np.array_equal(a["group_objects"], np.array([0, 1], np.float32))
+    # a single leaf terminates in every direction table; 0x7fffffff is stored as 2^31
+    for c in range(8):
+        assert np.array_equal(a[f"group_hitmiss_{c}"], np.array([2147483648.0] * 2, np.float32))
+    assert np.float32(2147483648.0) >= np.float32(16777215.0)   # terminator test of raytracer.es.fs:432
+    # boxes are inflated by 1e-5 (vectormath.h:189-195)
+    assert np.allclose(a["group_boxmin"], [-1e-5, -1e-5, -1e-5]) and np.allclose(a["group_boxmax"], [1 + 1e-5, 1 + 1e-5, 1e-5])
+
+
+def test_trisrc_truncated_record_fails(pkg, tmp_path):
+    with pytest.raises(RuntimeError):
+        pkg.World(write(tmp_path / "cut.trisrc", TRI + TRI[:60]))
+
+
+def test_trisrc_stops_quietly_at_foreign_text(pkg, tmp_path):
+    # the reference's scan loop ends (successfully) when the next record does not open with a quote
+    w = pkg.World(write(tmp_path / "tail.trisrc", TRI + "end of data\n"))
+    assert w.triangle_count == 1
+
+
+def test_empty_trisrc_gives_empty_world(pkg, tmp_path):
+    w = pkg.World(write(tmp_path / "empty.trisrc", ""))
+    a = w.arrays()
+    assert w.triangle_count == 0 and a["group_count"] == 1 and a["vertex_count"] == 0
+    assert np.array_equal(a["group_objects"], np.array([0, 0], np.float32))
+
+
+def test_unknown_extension_and_missing_file(pkg, tmp_path):
+    with pytest.raises(RuntimeError):
+        pkg.World(write(tmp_path / "scene.ply", "ply\n"))
+    with pytest.raises(RuntimeError):
+        pkg.World(str(tmp_path / "nope.obj"))
+
+
+def test_vertex_sharing_and_leaf_split(pkg, tmp_path):
+    # 12 triangles in a strip: more than bvh_leaf_max (10) -> one split, 3 nodes
+    rows = []
+    for k in range(12):
+        x = float(k)
+        rows.append('"*" t 0.5 0.5 0.5 1 20\n'
+                    f'{x} 0 0 0 0 1 1 1 1 1 0 0\n{x + 1} 0 0 0 0 1 1 1 1 1 0 0\n{x} 1 0 0 0 1 1 1 1 1 0 0\n')
+    w = pkg.World(write(tmp_path / "strip.trisrc", "".join(rows)))
+    a = w.arrays()
+    assert w.triangle_count == 12 and w.info.independent_vertex_count == 25   # (k,0) shared with (k-1)+1
+    assert a["group_count"] == 3 and a["tree_root"] == 1            # in-order numbering: root mid-array
+    objs = a["group_objects"].reshape(3, 2)
+    assert objs[1].tolist() == [0, 0] and objs[0, 0] == 0 and objs[0, 1] + objs[2, 1] == 12 and objs[2, 0] == objs[0, 1]
+    assert a["group_directions"].reshape(3, 3)[1].tolist() == [1, 0, 0]   # split along x
+    # code 1 (+x): negative child first; code 0 (-x): positive child first
+    hm1 = a["group_hitmiss_1"].reshape(3, 2)
+    hm0 = a["group_hitmiss_0"].reshape(3, 2)
+    assert hm1[1].tolist() == [0, 2147483648.0] and hm1[0].tolist() == [2, 2] and hm1[2].tolist() == [2147483648.0] * 2
+    assert hm0[1].tolist() == [2, 2147483648.0] and hm0[2].tolist() == [0, 0] and hm0[0].tolist() == [2147483648.0] * 2
+
+
+def test_obj_fan_triangulation_and_generated_normals(pkg, tmp_path):
+    text = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n"
+    w = pkg.World(write(tmp_path / "quad.obj", text))
+    a = w.arrays()
+    assert w.triangle_count == 2
+    assert np.array_equal(a["vertex_positions"].reshape(2, 3, 3)[1], np.array([[0, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32))
+    assert np.array_equal(a["vertex_normals"].reshape(6, 3), np.tile(np.array([0, 0, 1], np.float32), (6, 1)))
+    assert np.array_equal(a["vertex_colors"], np.ones(18, np.float32))
+
+
+def test_obj_trailing_blank_quirks(pkg, tmp_path):
+    # upstream's field splitter yields an extra empty field for a trailing blank: an attribute
+    # line then has 4 fields and stays (0,0,0)   (obj-support.cpp:61-82, :148-169)
+    text = "v 5 5 5 \nv 1 0 0\nv 0 1 0\nf 1 2 3\n"
+    w = pkg.World(write(tmp_path / "trail.obj", text))
+    assert np.array_equal(w.arrays()["vertex_positions"][:3], np.zeros(3, np.float32))
+
+
+def test_obj_bad_index_fails(pkg, tmp_path):
+    with pytest.raises(RuntimeError):
+        pkg.World(write(tmp_path / "bad.obj", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n"))
+
+
+def test_generators_are_deterministic(pkg, tmp_path):
+    import hashlib
+    p1, p2 = str(tmp_path / "a.trisrc"), str(tmp_path / "b.trisrc")
+    pos, tri = pkg.scenes.lobed_sphere_mesh(12, 24)
+    pkg.scenes.write_trisrc(p1, pos, tri)
+    pos, tri = pkg.scenes.lobed_sphere_mesh(12, 24)
+    pkg.scenes.write_trisrc(p2, pos, tri)
+    h = [hashlib.sha256(open(p, "rb").read()).hexdigest() for p in (p1, p2)]
+    assert h[0] == h[1]
+    assert len(tri) == 2 * 24 + 2 * 24 * 10
+    e1, e2 = pkg.scenes.environment_hdr_sky(64), pkg.scenes.environment_hdr_sky(64)
+    assert np.array_equal(e1, e2) and e1.max() > 10.0 and e1.dtype == np.float32
+    g = pkg.scenes.environment_grid(64)
+    assert g.shape == (32, 64, 3) and g[0].min() == 1.0 and g[1, 1].max() == 0.0 and g[3, 8].min() == 1.0

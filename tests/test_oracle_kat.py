@@ -1,0 +1,278 @@
+"""Analytic known-answer tests for the CPU oracle (oracle/shader_oracle.cpp).
+
+The reference has no tests or golden vectors for its per-pixel path (it exists only as
+GLSL), so these tests are what keeps an oracle bug from being silently mirrored by the
+kernel: each expected value is derived here, independently, from the shader text
+(file:line cited) -- closed forms in numpy float64, compared at float32 precision."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import END, HandScene, default_params, single_leaf_scene
+
+
+def filmic64(c):   # raytracer.es.fs:527-531
+    x = np.maximum(0.0, np.asarray(c, dtype=np.float64) - 0.004)
+    return (x * (6.2 * x + 0.5)) / (x * (6.2 * x + 1.7) + 0.06)
+
+
+def env_bilinear64(env, d):
+    """raytracer.es.fs:130 + GL bilinear/REPEAT, in float64."""
+    d = np.asarray(d, np.float64)
+    h, w, _ = env.shape
+    s = 1.0 + np.arctan2(-d[2], d[0]) / (2 * np.pi)
+    t = 1.0 - np.arccos(np.clip(d[1], -1, 1)) / np.pi
+    u, v = s * w - 0.5, t * h - 0.5
+    i0, j0 = int(np.floor(u)), int(np.floor(v))
+    a, b = u - i0, v - j0
+    e = env.astype(np.float64)
+    px = lambda i, j: e[j % h, i % w]
+    return (1 - a) * (1 - b) * px(i0, j0) + a * (1 - b) * px(i0 + 1, j0) + (1 - a) * b * px(i0, j0 + 1) + a * b * px(i0 + 1, j0 + 1)
+
+
+def pixel_dir64(p, px, py, W, H):
+    """raytracer.vs:39-49 at the pixel centre, camera looking down -z."""
+    u, v = (px + 0.5) / W, (py + 0.5) / H
+    d = np.array([p.image_plane_width * (u - 0.5), p.image_plane_width * (v - 0.5) * p.aspect, -1.0])
+    return d / np.linalg.norm(d)
+
+
+def test_filmic_spot_values(oracle_mod):
+    for c in (0.0, 0.004, 0.01, 0.18, 0.5, 1.0, 4.0, 60.0):
+        assert oracle_mod.filmic(c) == pytest.approx(float(filmic64(c)), rel=2e-6, abs=1e-9)
+    assert oracle_mod.filmic(0.0) == 0.0 and oracle_mod.filmic(-3.0) == 0.0
+
+
+def test_half_rounding(oracle_mod):
+    h = oracle_mod.half
+    assert h(1.0) == 1.0 and h(-0.5) == -0.5 and h(0.0) == 0.0
+    assert h(1.0 + 2.0 ** -11) == 1.0                 # tie -> even
+    assert h(1.0 + 3 * 2.0 ** -11) == 1.0 + 2.0 ** -9  # tie -> even (up)
+    assert h(1.0 + 2.0 ** -11 + 2.0 ** -20) == 1.0 + 2.0 ** -10
+    assert h(0.333333343267) == np.float32(np.float16(np.float32(0.333333343267)))
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-1, 1, 2000), rng.uniform(-1e-4, 1e-4, 500), rng.uniform(-7e-8, 7e-8, 200)]).astype(np.float32)
+    for x in xs:
+        assert h(float(x)) == float(np.float32(np.float16(x))), x
+
+
+def test_schlick_endpoints(oracle_mod):
+    c = (1.0, 0.71, 0.29)
+    v = (0.0, 0.0, -1.0)
+    # dot(v, r) = 1 -> pow(1, 5) = 1 -> white; dot = -1 -> pow(0, 5) = 0 -> cspec (raytracer.es.fs:479-482)
+    assert np.array_equal(oracle_mod.schlick(c, v, v), np.ones(3, np.float32))
+    assert np.array_equal(oracle_mod.schlick(c, v, (0.0, 0.0, 1.0)), np.array(c, np.float32))
+
+
+def test_primary_ray_matches_vertex_shader(pkg, oracle_mod):
+    p = default_params(pkg, 1920, 1080, zoom=2.5)
+    for (px, py) in ((0, 0), (959, 540), (1919, 1079), (100, 900)):
+        o, d = oracle_mod.primary_ray(p, (px + 0.5) / 1920, (py + 0.5) / 1080)
+        assert np.array_equal(o, np.array([0, 0, 2.5], np.float32))
+        assert np.allclose(d, pixel_dir64(p, px, py, 1920, 1080), rtol=0, atol=2e-7)
+    # v = 0 is the BOTTOM of the image (raytracer.vs:43-44, :56)
+    assert oracle_mod.primary_ray(p, 0.5, 0.0)[1][1] < 0 < oracle_mod.primary_ray(p, 0.5, 1.0)[1][1]
+
+
+def far_away_triangle():
+    return single_leaf_scene([[[100, 100, 100], [101, 100, 100], [100, 101, 100]]])
+
+
+def test_env_only_pixels_are_tonemapped_bilinear_samples(pkg, oracle_mod):
+    scene = far_away_triangle()   # nothing in view
+    env = pkg.scenes.environment_hdr_sky(64)
+    W, H = 48, 32
+    p = default_params(pkg, W, H)
+    img, c = oracle_mod.render(scene.desc, env, p, W, H)
+    assert c["env_lookups"] == W * H and c["shaded_hits"] == 0 and c["traversals"] == W * H
+    assert c["node_visits"] == W * H and c["triangle_tests"] == 0     # one box test, missed
+    for (px, py) in ((0, 0), (47, 31), (10, 20), (24, 16), (33, 3)):
+        want = filmic64(env_bilinear64(env, pixel_dir64(p, px, py, W, H)))
+        assert np.allclose(img[py, px, :3], want, rtol=2e-5, atol=1e-6), (px, py)
+    assert np.all(img[..., 3] == 1.0)
+
+
+def test_env_wraps_in_s_and_t(pkg, oracle_mod):
+    """A 2x2 environment: looking straight up / down blends the rows across the t wrap
+    (GL REPEAT is the default for both axes; ray.cpp:499-510 sets no wrap mode)."""
+    scene = far_away_triangle()
+    env = np.array([[[1, 0, 0], [0, 1, 0]], [[0, 0, 1], [1, 1, 1]]], np.float32)
+    p = default_params(pkg, 4, 4)
+    p.tonemap = 0
+    # aim the camera straight up: rotate eye -z onto +y via camera_normal_matrix
+    rot = np.array([1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1], np.float32)   # column-major: world = (x, -z, y)
+    p.camera_normal_matrix[:] = rot.tolist()
+    img, _ = oracle_mod.render(scene.desc, env, p, 4, 4)
+    for py in range(4):
+        for px in range(4):
+            e = pixel_dir64(p, px, py, 4, 4)
+            d = np.array([e[0], -e[2], e[1]])
+            assert np.allclose(img[py, px, :3], env_bilinear64(env, d), rtol=1e-4, atol=1e-5)
+
+
+def mirror_quad(z=0.0, half=10.0):
+    a, b, c, d = [-half, -half, z], [half, -half, z], [half, half, z], [-half, half, z]
+    return [[a, b, c], [a, c, d]]
+
+
+def test_single_mirror_bounce_closed_form(pkg, oracle_mod):
+    """Camera on +z looking at a big mirror in the z = 0 plane: every pixel hits once at
+    t = zoom / -D.z, reflects to (D.x, D.y, -D.z), and returns F * env(R) with Schlick's F
+    (raytracer.es.fs:484-522, :552-582); the flat normal is exact in fp16."""
+    scene = single_leaf_scene(mirror_quad())
+    env = pkg.scenes.environment_hdr_sky(64)
+    W, H = 40, 24
+    zoom = 3.0
+    p = default_params(pkg, W, H, zoom=zoom, material=0)
+    img, c = oracle_mod.render(scene.desc, env, p, W, H)
+    assert c["shaded_hits"] == W * H and c["env_lookups"] == W * H
+    assert c["traversals"] == 2 * W * H            # second bounce leaves the scene
+    assert c["triangle_tests"] == 2 * W * H        # both triangles once; the bounced ray starts past the box
+    assert c["node_visits"] == 2 * W * H
+    spec = np.array([1, .71, .29])
+    for (px, py) in ((0, 0), (39, 23), (20, 12), (7, 19)):
+        D = pixel_dir64(p, px, py, W, H)
+        R = D * np.array([1, 1, -1])
+        F = spec + (1 - spec) * (np.dot(D, R) * .5 + .5) ** 5
+        want = filmic64(F * env_bilinear64(env, R))
+        assert np.allclose(img[py, px, :3], want, rtol=3e-5, atol=1e-6), (px, py)
+
+
+def test_diffuse_shading_and_shadow(pkg, oracle_mod):
+    """Glazed plaster on the same mirror quad: accumulated = diffuse * max(0, n.l) (unshadowed,
+    raytracer.es.fs:447-472) plus F * env(R); then a blocker between surface and light
+    removes the diffuse term."""
+    env = pkg.scenes.environment_constant((0.2, 0.3, 0.4))
+    W, H = 16, 16
+    p = default_params(pkg, W, H, zoom=3.0, material=6)
+    light = np.array(p.light_dir[:], np.float64)
+    spec = np.array([.05, .05, .05])
+
+    def expected(px, py, lit):
+        D = pixel_dir64(p, px, py, W, H)
+        R = D * np.array([1, 1, -1])
+        F = spec + (1 - spec) * (np.dot(D, R) * .5 + .5) ** 5
+        diffuse = max(0.0, light[2]) if lit else 0.0
+        return filmic64(diffuse + F * np.array([0.2, 0.3, 0.4]))
+
+    scene = single_leaf_scene(mirror_quad())
+    img, c = oracle_mod.render(scene.desc, env, p, W, H)
+    assert c["traversals"] == 3 * W * H   # closest hit, shadow ray, second bounce (which misses)
+    for (px, py) in ((0, 0), (8, 8), (15, 3)):
+        assert np.allclose(img[py, px, :3], expected(px, py, True), rtol=3e-5, atol=1e-6)
+
+    # blocker: a huge quad high above, facing down, hides the light from everything
+    blocker = [[[-500, -500, 50], [500, 500, 50], [500, -500, 50]], [[-500, -500, 50], [-500, 500, 50], [500, 500, 50]]]
+    scene2 = single_leaf_scene(mirror_quad() + blocker)
+    p2 = default_params(pkg, W, H, zoom=3.0, material=6)
+    p2.bounce_count = 1
+    img2, _ = oracle_mod.render(scene2.desc, env, p2, W, H)
+    for (px, py) in ((0, 0), (8, 8), (15, 3)):
+        assert np.allclose(img2[py, px, :3], expected(px, py, False), rtol=3e-5, atol=1e-6)
+
+
+def test_leaf_tests_only_its_first_ten_triangles(pkg, oracle_mod):
+    """max_leaf_tests = 10 (raytracer.es.fs:382, :412-417): the 11th triangle of a leaf is
+    never tested, even when it is the nearest."""
+    quads = []
+    for k in range(10):
+        z = -float(k)
+        quads.append([[-5, -5, z], [5, -5, z], [0, 5, z]])
+    quads.append([[-5, -5, 1.0], [5, -5, 1.0], [0, 5, 1.0]])   # nearest to the camera, index 10
+    scene = single_leaf_scene(quads)
+    env = pkg.scenes.environment_constant((1, 1, 1))
+    p = default_params(pkg, 8, 8, zoom=4.0)
+    p.bounce_count = 1
+    p.tonemap = 0
+    _, c = oracle_mod.render(scene.desc, env, p, 8, 8)
+    assert c["triangle_tests"] == 10 * c["leaf_visits"] == 10 * 64
+    # with the cap lifted the 11th is tested too
+    p.max_leaf_tests = 11
+    _, c = oracle_mod.render(scene.desc, env, p, 8, 8)
+    assert c["triangle_tests"] == 11 * 64
+
+
+def chain_scene(n):
+    """n leaf nodes threaded one after another, each an empty leaf whose box covers the view."""
+    hm = np.zeros((8, n, 2), np.float32)
+    for g in range(n):
+        hm[:, g, :] = (g + 1) if g + 1 < n else END
+    lo = np.tile([-50, -50, -50], (n, 1))
+    hi = np.tile([50, 50, 50], (n, 1))
+    objs = np.zeros((n, 2), np.float32)
+    tri = [[100, 100, 100], [101, 100, 100], [100, 101, 100]]
+    return HandScene(tri, [[0, 0, 1]] * 3, lo, hi, hm, objs, 0)
+
+
+def test_iteration_cap_gives_the_red_marker(pkg, oracle_mod):
+    """400 iterations without reaching a terminator -> (1,0,0), unmodulated, then tone-mapped
+    (raytracer.es.fs:436-438, :497-501, :566-568); exactly 400 nodes still terminate."""
+    env = pkg.scenes.environment_constant((0.5, 0.5, 0.5))
+    p = default_params(pkg, 4, 4)
+    img, c = oracle_mod.render(chain_scene(401).desc, env, p, 4, 4)
+    red = filmic64([1.0, 0.0, 0.0])
+    assert np.allclose(img[..., :3], red, rtol=1e-6) and c["bad_hits"] == 16 and c["node_visits"] == 16 * 400
+    assert c["env_lookups"] == 0
+    img, c = oracle_mod.render(chain_scene(400).desc, env, p, 4, 4)
+    assert c["bad_hits"] == 0 and c["node_visits"] == 16 * 400
+    assert np.allclose(img[..., :3], filmic64([0.5, 0.5, 0.5]), rtol=1e-6)
+
+
+def test_sphere_hit_distance_and_normal(pkg, oracle_mod, tmp_path):
+    """Tessellated unit sphere, white constant environment, gold, one bounce: every pixel
+    that hits returns F * 1; with smooth normals F depends on the normal only, so the
+    central pixel (normal ~ +z, head-on) must give F = cspec exactly-ish."""
+    pos, tri = pkg.scenes.lobed_sphere_mesh(48, 96, bumpiness=0.0, ears=False)
+    path = str(tmp_path / "sphere.trisrc")
+    pkg.scenes.write_trisrc(path, pos, tri)
+    world = pkg.World(path)
+    desc = world.flatten()
+    env = pkg.scenes.environment_constant((1, 1, 1))
+    W = H = 33
+    p = world.frame_params(W, H, material=0)
+    p.bounce_count = 1
+    p.tonemap = 0
+    img, c = oracle_mod.render(desc, env, p, W, H)
+    centre = img[16, 16, :3]
+    assert np.allclose(centre, [1, .71, .29], atol=2e-3)          # head-on: pow(~0, 5) ~ 0
+    corner = img[0, 0, :3]
+    assert np.all(corner > 0.99999)                               # missed: environment only (weights sum to 1 - ulp)
+    # silhouette of a unit sphere seen from `zoom` under fov 40: hit iff the ray passes within r = 1
+    zoom = world.default_view().zoom
+    hits = 0
+    for py in range(H):
+        for px in range(W):
+            D = pixel_dir64(p, px, py, W, H)
+            closest = np.linalg.norm(np.cross(np.array([0, 0, zoom]) - np.array(world.info.scene_center[:]), D))
+            if closest < 0.995:
+                assert img[py, px, 2] < 0.99, (px, py)       # hit: Fresnel-weighted, blue < 1
+                hits += 1
+            elif closest > 1.0 + 1e-3:
+                assert np.all(img[py, px, :3] > 0.99999), (px, py)
+    assert hits > 200 and c["shaded_hits"] >= hits
+
+
+def test_spp_average_of_constant_is_constant(pkg, oracle_mod):
+    scene = far_away_triangle()
+    env = pkg.scenes.environment_constant((0.25, 0.5, 2.0))
+    p = default_params(pkg, 6, 5)
+    one, _ = oracle_mod.render(scene.desc, env, p, 6, 5, spp=1)
+    many, c = oracle_mod.render(scene.desc, env, p, 6, 5, spp=7)
+    assert c["samples"] == 6 * 5 * 7 and c["env_lookups"] == 6 * 5 * 7
+    assert np.allclose(one, many, rtol=1e-6)
+
+
+def test_golden_frames_still_reproduce(pkg, oracle_mod):
+    """The committed oracle frames (tests/golden/lobed_528.oracle.npz) pin today's oracle."""
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    frames = np.load(os.path.join(golden, "lobed_528.oracle.npz"))
+    world = pkg.World(os.path.join(golden, "lobed_528.trisrc"))
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(128)
+    for name, material in (("gold", 0), ("plaster", 6)):
+        img, counters = oracle_mod.render(desc, env, world.frame_params(64, 64, material=material), 64, 64)
+        helpers.assert_images_match(img, frames[name], name)
+        assert [counters[k] for k in sorted(counters)] == frames[name + "_counters"].tolist()

@@ -34,6 +34,10 @@ def load():
         _lib.shray_oracle_filmic.argtypes = [C.c_float]
         _lib.shray_oracle_half.restype = C.c_float
         _lib.shray_oracle_half.argtypes = [C.c_float]
+        for name, nargs in (("shray_oracle_atan2", 2), ("shray_oracle_acos", 1), ("shray_oracle_pow5", 1)):
+            fn = getattr(_lib, name)
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float] * nargs
     return _lib
 
 
@@ -63,6 +67,18 @@ def filmic(c: float) -> float:
 
 def half(f: float) -> float:
     return float(load().shray_oracle_half(C.c_float(f)))
+
+
+def atan2(y: float, x: float) -> float:
+    return float(load().shray_oracle_atan2(y, x))
+
+
+def acos(x: float) -> float:
+    return float(load().shray_oracle_acos(x))
+
+
+def pow5(x: float) -> float:
+    return float(load().shray_oracle_pow5(x))
 
 
 def schlick(cspec, v, r):

@@ -25,10 +25,17 @@
 //     reflect    = I - (2*dot(N,I))*N                    (GLSL 1.40 spec 8.4)
 //     max(x,y)   = x < y ? y : x;  min(x,y) = y < x ? y : x   (spec 8.3)
 //     mat4*vec4  = sum over columns, x..w in order
-//   * atan(y,x) -> atan2f, acos -> acosf with the argument clamped to [-1,1]
-//     (GLSL leaves |x|>1 undefined, fs:130), pow -> powf.  These three are the
-//     only operations not bit-reproducible across libm/ocml; they feed only
-//     continuous quantities, hence the 1e-4 relative tolerance.
+//   * the three transcendental built-ins the path uses are specified as
+//     explicit fp32 operation sequences (GLSL only bounds their precision
+//     loosely), so that the whole path is bit-reproducible on any IEEE machine:
+//       atan(y,x) -> sr_atan2: octant reduction + the odd degree-9 polynomial
+//                    derived by oracle/tools/fit_atan.py (max error 2.8 ulp)
+//       acos(x)   -> sr_atan2(sqrt((1-x)*(1+x)), x), x clamped to [-1,1]
+//                    (GLSL leaves |x| > 1 undefined, fs:130)
+//       pow(x,5.) -> ((x*x)*(x*x))*x                       (fs:481)
+//     The C library's versions differ by an ulp between glibc and the GPU's
+//     ocml, and a sharp environment map (the reference's own `grid`) amplifies
+//     that beyond 1e-4 relative; with the explicit forms CPU and GPU agree exactly.
 //   * data textures are NEAREST-filtered (ray.cpp:351-352) and index_to_sample
 //     (fs:239-245) lands in texel (which mod W, which div W): plain array reads.
 //     All indices are float32 values (exact below 2^24).
@@ -76,6 +83,40 @@ inline vec3 normalize(vec3 a) { return a / sqrtf(dot(a, a)); }
 inline vec3 reflect(vec3 I, vec3 N) { return I - (2.0f * dot(N, I)) * N; }
 inline float gl_max(float x, float y) { return x < y ? y : x; }
 inline float gl_min(float x, float y) { return y < x ? y : x; }
+
+// atan(y, x), see the header: one rounding per operation, nothing fused
+inline float sr_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax < ay ? ay : ax;
+    const float mn = ax < ay ? ax : ay;
+    if (mx == 0.0f)
+        return 0.0f;
+    const float a = mn / mx;
+    const bool upper = a > 0.414213562f;                    // tan(pi/8)
+    const float z = upper ? (a - 1.0f) / (a + 1.0f) : a;
+    const float s = z * z;
+    float p = 0.0803788006f * s;
+    p = (p + -0.138722613f) * s;
+    p = (p + 0.199771404f) * s;
+    p = p + -0.33332932f;
+    float r = z + (z * s) * p;
+    if (upper)
+        r = 0.785398163f + r;
+    if (ay > ax)
+        r = 1.57079633f - r;
+    if (x < 0.0f)
+        r = 3.14159265f - r;
+    if (y < 0.0f)
+        r = -r;
+    return r;
+}
+inline float sr_acos(float x) { return sr_atan2(sqrtf((1.0f - x) * (1.0f + x)), x); }
+inline float sr_pow5(float x)
+{
+    const float x2 = x * x;
+    return (x2 * x2) * x;
+}
 
 // mat4 * vec4(v, w), column-major storage
 inline vec3 transform(const float m[16], vec3 v, float w)
@@ -328,7 +369,7 @@ vec3 approximate_diffuse(Ctx &cx, vec3 point, vec3 normal)
 // fs:479-482
 inline vec3 f_schlick_vr(vec3 cspec, vec3 v, vec3 r)
 {
-    const float w = powf(dot(v, r) * .5f + .5f, 5.0f);
+    const float w = sr_pow5(dot(v, r) * .5f + .5f);
     return cspec + (V(1.0f, 1.0f, 1.0f) - cspec) * w;
 }
 
@@ -375,8 +416,8 @@ vec3 sample_environment(Ctx &cx, const ray &r)
     cx.c.env_lookups++;
     const Scene &sc = *cx.scene;
     const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
-    const float s = 1.0f + atan2f(-r.D.z, r.D.x) / tau;
-    const float t = 1.0f - acosf(dy) / pi;
+    const float s = 1.0f + sr_atan2(-r.D.z, r.D.x) / tau;
+    const float t = 1.0f - sr_acos(dy) / pi;
     const float fw = (float)sc.env_w, fh = (float)sc.env_h;
     const float u = s * fw - 0.5f;
     const float v = t * fh - 0.5f;
@@ -545,6 +586,9 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
 // Pieces exposed for the known-answer tests.
 float shray_oracle_filmic(float c) { return filmic(c); }
 float shray_oracle_half(float f) { return round_through_half(f); }
+float shray_oracle_atan2(float y, float x) { return sr_atan2(y, x); }
+float shray_oracle_acos(float x) { return sr_acos(x); }
+float shray_oracle_pow5(float x) { return sr_pow5(x); }
 void shray_oracle_schlick(const float cspec[3], const float v[3], const float r[3], float out[3])
 {
     const vec3 f = f_schlick_vr(V(cspec[0], cspec[1], cspec[2]), V(v[0], v[1], v[2]), V(r[0], r[1], r[2]));

@@ -11,8 +11,9 @@
 //   raytracer.es.fs:527-548 filmic tone map
 // Arithmetic contract (identical to the CPU oracle's; DESIGN.md "Arithmetic"):
 // single-rounded IEEE fp32 operations in the shader's order, compiled with
-// -ffp-contract=off and correctly rounded divide/sqrt; only atan2f / acosf /
-// powf are library calls.
+// -ffp-contract=off and correctly rounded divide/sqrt.  atan / acos / pow(x,5)
+// are explicit fp32 operation sequences (atan_yx, acos_clamped, pow5 below),
+// not library calls, so a frame is bit-reproducible against the CPU oracle.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -39,6 +40,35 @@ __device__ __forceinline__ V3 unit(V3 a) { return a / sqrtf(dot3(a, a)); }
 // GLSL max/min: the SECOND operand wins only on a strict compare
 __device__ __forceinline__ float sel_max(float x, float y) { return x < y ? y : x; }
 __device__ __forceinline__ float sel_min(float x, float y) { return y < x ? y : x; }
+
+// atan(y, x): octant reduction, then z + z^3 * P(z^2) on |z| <= tan(pi/8);
+// coefficients from oracle/tools/fit_atan.py (max error 2.8 ulp).
+__device__ __forceinline__ float atan_yx(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = ax < ay ? ay : ax, lo = ax < ay ? ax : ay;
+    if (hi == 0.0f)
+        return 0.0f;
+    const float q = lo / hi;
+    const bool fold = q > 0.414213562f;
+    const float z = fold ? (q - 1.0f) / (q + 1.0f) : q;
+    const float zz = z * z;
+    float poly = 0.0803788006f * zz;
+    poly = (poly + -0.138722613f) * zz;
+    poly = (poly + 0.199771404f) * zz;
+    poly = poly + -0.33332932f;
+    float angle = z + (z * zz) * poly;
+    angle = fold ? 0.785398163f + angle : angle;
+    angle = ay > ax ? 1.57079633f - angle : angle;
+    angle = x < 0.0f ? 3.14159265f - angle : angle;
+    return y < 0.0f ? -angle : angle;
+}
+__device__ __forceinline__ float acos_clamped(float c) { return atan_yx(sqrtf((1.0f - c) * (1.0f + c)), c); }
+__device__ __forceinline__ float pow5(float b)
+{
+    const float b2 = b * b;
+    return (b2 * b2) * b;
+}
 
 // column-major mat4 times (v, w)
 __device__ __forceinline__ V3 xform(const float *m, V3 v, float w)
@@ -91,8 +121,8 @@ __device__ __forceinline__ V3 environment(const SceneView &sc, V3 d)
 {
     const float tau = 2 * kPi;
     const float dy = sel_min(sel_max(d.y, -1.0f), 1.0f);
-    const float s = 1.0f + atan2f(-d.z, d.x) / tau;
-    const float t = 1.0f - acosf(dy) / kPi;
+    const float s = 1.0f + atan_yx(-d.z, d.x) / tau;
+    const float t = 1.0f - acos_clamped(dy) / kPi;
     const float u = s * (float)sc.env_w - 0.5f;
     const float v = t * (float)sc.env_h - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
@@ -155,7 +185,7 @@ __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr
         const V3 at = P + D * hit.t;                      // ray_transfer, fs:69
         const V3 R = D - n * (2.0f * dot3(n, D));         // reflect(), fs:86
         const V3 P2 = at + n * .0001f;                    // surface fudge, fs:87
-        const float fresnel = powf(dot3(D, R) * .5f + .5f, 5.0f);
+        const float fresnel = pow5(dot3(D, R) * .5f + .5f);
         const V3 object_specular = spec + (mk(1.0f, 1.0f, 1.0f) - spec) * fresnel;   // f_schlick_vr, fs:479-482
 
         if (has_diffuse) {

@@ -41,6 +41,10 @@ def check_against_oracle(oracle_mod, scene, desc, env, params, W, H, spp, what):
         got, gpu_counters = scene.render_counters(params, W, H, spp)
         plain = scene.render(params, W, H, spp)
         assert_images_match(got, want, f"{what} kernel {kernel}")
+        # stronger than the 1e-4 bar: every operation on the path is a specified IEEE fp32
+        # operation on both sides, so the frames are expected to be bit-identical
+        differing = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert differing == 0, f"{what} kernel {kernel}: {differing} floats are not bit-identical to the oracle"
         assert np.array_equal(plain, got), f"{what} kernel {kernel}: plain and counting kernels differ"
         assert gpu_counters == cpu, f"{what} kernel {kernel}: counters {gpu_counters} != oracle {cpu}"
     scene.set_kernel(0)

@@ -276,3 +276,23 @@ def test_golden_frames_still_reproduce(pkg, oracle_mod):
         img, counters = oracle_mod.render(desc, env, world.frame_params(64, 64, material=material), 64, 64)
         helpers.assert_images_match(img, frames[name], name)
         assert [counters[k] for k in sorted(counters)] == frames[name + "_counters"].tolist()
+
+
+def test_specified_transcendentals_are_accurate(oracle_mod):
+    """sr_atan2 / sr_acos / sr_pow5 replace the GLSL built-ins atan, acos, pow(x, 5.0)
+    (raytracer.es.fs:130, :481) with explicit fp32 sequences; they must still BE those
+    functions: within 4 ulp of the float64 value (GLSL itself allows far more)."""
+    rng = np.random.default_rng(5)
+    for _ in range(4000):
+        y, x = (float(np.float32(v)) for v in rng.uniform(-1, 1, 2))
+        want = np.arctan2(np.float64(y), np.float64(x))
+        ulp = float(np.spacing(np.float32(abs(want)))) or 1e-45
+        assert abs(oracle_mod.atan2(y, x) - want) <= 4 * ulp, (y, x)
+    for c in np.concatenate([rng.uniform(-1, 1, 3000), [1.0, -1.0, 0.0, 0.99999994, -0.99999994]]):
+        c = float(np.float32(c))
+        want = np.arccos(np.float64(c))
+        assert abs(oracle_mod.acos(c) - want) <= 4 * float(np.spacing(np.float32(max(want, 1e-3)))), c
+    assert oracle_mod.acos(1.0) == 0.0 and oracle_mod.atan2(0.0, 1.0) == 0.0
+    assert oracle_mod.atan2(0.0, -1.0) == float(np.float32(np.pi)) and oracle_mod.atan2(1.0, 0.0) == float(np.float32(np.pi / 2))
+    for b in (0.0, 1.0, 0.5, 0.999, 1e-3, 0.37):
+        assert oracle_mod.pow5(b) == pytest.approx(b ** 5, rel=4e-7, abs=1e-45)

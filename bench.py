@@ -42,7 +42,7 @@ def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
     t0 = time.perf_counter()
     oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)
     first = time.perf_counter() - t0
-    reps = max(1, min(20, int(budget_s / max(first, 1e-3)) - 1))
+    reps = max(1, min(500, int(budget_s / max(first, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(reps):
         oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)

@@ -4,6 +4,12 @@ import numpy as np
 
 
 def run_smoke():
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
     import helpers
     import oracle
     from __graft_entry__ import load_package

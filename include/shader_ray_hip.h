@@ -195,6 +195,13 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params,
                           float *rgba_out_host /* may be NULL */,
                           shray_counters *counters);
 
+/* Self-test ---------------------------------------------------------------- */
+/* Runs the kernel's 5-instruction "divide by a per-ray constant" (csrc/exact_div.h)
+ * against true IEEE division on `pairs` pseudo-random operand pairs from the operand
+ * ranges it is used in, plus structured hard cases; *mismatches = number of pairs whose
+ * results are not bit-identical (must be 0). */
+int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,7 @@ HIP_SYMBOLS = [
     ("shray_tile_buffer_bytes", C.c_int64, [C.c_int, C.c_int, C.POINTER(TileSet)]),
     ("shray_render_counters", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                         c_float_p, C.POINTER(Counters)]),
+    ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
 ]
 
 HOST_SYMBOLS = [

@@ -471,6 +471,19 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         HIP_TRY(s->packed_nodes.upload(nodes.data(), nodes.size() * sizeof(PackedNode)));
         HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
         s->view.packed_root = packed_root;
+        // operand-range condition of exact_div.h on the scene's side: every box coordinate
+        // is zero or has magnitude in [2^-70, 2^60)
+        bool coords_ok = true;
+        for (const PackedNode &pn : nodes) {
+            for (int k = 0; k < 3 && coords_ok; k++) {
+                for (float c : {pn.lo[k], pn.hi[k]}) {
+                    const float m = fabsf(c);
+                    if (!(c == 0.0f || (m >= 0x1p-70f && m < 0x1p60f)))
+                        coords_ok = false;
+                }
+            }
+        }
+        s->view.exact_div_ok = coords_ok ? 1u : 0u;
         s->stack_levels = std::max(1, depth);
         s->packed_ok = true;
     }
@@ -613,6 +626,22 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
     counters->traversals = dc.traversals;
     counters->bad_hits = dc.bad_hits;
     counters->samples = (uint64_t)width * height * spp;
+    return SHRAY_OK;
+}
+
+int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches)
+{
+    if (!mismatches)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "mismatches is NULL");
+    DeviceBuffer count;
+    HIP_TRY(count.upload(nullptr, sizeof(unsigned long long)));
+    hipError_t e = shray::launch_division_selftest(pairs, seed, (unsigned long long *)count.p, nullptr);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "self-test launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, count.p, sizeof(n), hipMemcpyDeviceToHost));
+    *mismatches = n;
     return SHRAY_OK;
 }
 

@@ -36,6 +36,7 @@ struct SceneView {
     const void *packed_nodes;   // PackedNode[group_count]
     const void *packed_tris;    // PackedTri[triangle_count]
     uint32_t packed_root;
+    uint32_t exact_div_ok;      // every box coordinate is 0 or in [2^-70, 2^60): exact_div.h applies
 
     const float *env;   // RGB f32, row 0 = t = 0 (straight down)
     int32_t env_w, env_h;

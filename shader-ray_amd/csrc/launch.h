@@ -14,4 +14,9 @@ hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out
 hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
                         hipStream_t stream, int stack_levels);
 
+// Compares div_by_constant (exact_div.h) with true division on `pairs` pseudo-random
+// operand pairs drawn from the admitted ranges; *mismatches receives the count.
+hipError_t launch_division_selftest(unsigned long long pairs, unsigned long long seed,
+                                    unsigned long long *mismatches, hipStream_t stream);
+
 }   // namespace shray

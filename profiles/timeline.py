@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-wave residency timeline of one bench frame (diagnostic build, `make -C shader-ray_amd diag`).
+
+Prints: kernel span, distribution of wave durations, occupancy over time (resident waves per
+CU in 20 slices of the kernel span), and the busiest / idlest CUs.  Usage (GPU box):
+    python profiles/timeline.py [--kernel 0|1] [--width 1920 --height 1080]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--material", type=int, default=0)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (one HIP runtime)
+    from __graft_entry__ import load_package
+    import helpers
+    pkg = load_package()
+    N = pkg._native
+    N.HIP_LIB = os.path.join(N.PKG_DIR, "libshray_hip_diag.so")
+    lib = N.load_hip()
+    lib.shray_debug_timeline.restype = C.c_int
+    world = pkg.World(helpers.bunny_trisrc())
+    desc = world.flatten()
+    scene = pkg.Scene(desc, pkg.scenes.environment_hdr_sky(2048), device=0)
+    scene.set_kernel(args.kernel)
+    W, H = args.width, args.height
+    params = world.frame_params(W, H, material=args.material)
+    patches = ((W + 15) // 16) * ((H + 15) // 16)
+    stamps = np.zeros((patches * 4, 4), dtype=np.uint64)
+    N.check(lib.shray_debug_timeline(scene._handle, C.byref(params), W, H, 1, stamps.ctypes.data_as(C.c_void_p)))
+    t0 = stamps[:, 0].astype(np.float64)
+    t1 = stamps[:, 1].astype(np.float64)
+    hw = (stamps[:, 2] & np.uint64(0xffffffff)).astype(np.uint32)
+    xcc = (stamps[:, 2] >> np.uint64(32)).astype(np.uint32)
+    # HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+    cu = (hw >> 8) & 0xf
+    sh = (hw >> 12) & 0x1
+    se = (hw >> 13) & 0x7
+    cu_key = xcc * 1000 + se * 100 + sh * 10 + cu
+    start = t0.min()
+    span = t1.max() - start
+    dur = (t1 - t0) * 10e-3   # 100 MHz ticks -> microseconds
+    print(f"kernel span {span * 10e-3:.1f} us, {len(dur)} waves, {len(np.unique(cu_key))} distinct CUs seen")
+    q = np.percentile(dur, [0, 10, 50, 90, 99, 100])
+    print("wave duration us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; mean %.1f" % (*q, dur.mean()))
+    print(f"sum of wave durations / span = {dur.sum() / (span * 10e-3):.0f} waves resident on average "
+          f"({dur.sum() / (span * 10e-3) / 256:.2f} per CU)")
+    slices = 20
+    edges = start + np.linspace(0, span, slices + 1)
+    print("slice  resident-waves(avg)  waves-started")
+    for k in range(slices):
+        a, b = edges[k], edges[k + 1]
+        overlap = np.clip(np.minimum(t1, b) - np.maximum(t0, a), 0, None).sum() / (b - a)
+        started = int(((t0 >= a) & (t0 < b)).sum())
+        print(f"{k:5d}  {overlap:10.0f}  {started:8d}")
+    # heavy waves: where are they in the frame and when do they start?
+    order = np.argsort(-dur)[:10]
+    px = ((W + 15) // 16)
+    for i in order:
+        blk = i // 4
+        print(f"heavy wave: block ({blk % px},{blk // px}) wave {i % 4} dur {dur[i]:.1f} us start +{(t0[i] - start) * 10e-3:.1f} us "
+              f"lane0 node visits {int(stamps[i, 3])}")
+    busy = {}
+    for k, d in zip(cu_key, dur):
+        busy[k] = busy.get(k, 0.0) + d
+    vals = np.array(sorted(busy.values()))
+    print("per-CU summed wave time us: min %.0f p50 %.0f max %.0f" % (vals[0], vals[len(vals) // 2], vals[-1]))
+
+
+if __name__ == "__main__":
+    main()

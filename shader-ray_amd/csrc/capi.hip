@@ -629,6 +629,35 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
     return SHRAY_OK;
 }
 
+#ifdef SHRAY_DIAGNOSTICS
+// Diagnostic build only (libshray_hip_diag.so, profiles/timeline.py): renders one frame with
+// the counting kernel and returns 4 x uint64 per wave {begin, end (100 MHz ticks), xcc<<32|hw_id,
+// lane-0 node visits}; `stamps` must hold 16 * ceil(w/16) * ceil(h/16) values.
+int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                         uint64_t *stamps)
+{
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    FrameView fr;
+    rc = make_frame_view(params, width, height, spp, nullptr, &fr);
+    if (rc)
+        return rc;
+    const size_t nstamps = (size_t)fr.total_patches * 16;
+    DeviceBuffer frame, dbg;
+    HIP_TRY(frame.upload(nullptr, (size_t)width * height * 16));
+    HIP_TRY(dbg.upload(nullptr, sizeof(DeviceCounters) + nstamps * 8));
+    for (int rep = 0; rep < 3; rep++) {   // warm caches; the last run's stamps are returned
+        rc = launch(scene, fr, (float4 *)frame.p, (DeviceCounters *)dbg.p, nullptr);
+        if (rc)
+            return rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    HIP_TRY(hipMemcpy(stamps, (char *)dbg.p + sizeof(DeviceCounters), nstamps * 8, hipMemcpyDeviceToHost));
+    return SHRAY_OK;
+}
+#endif
+
 int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches)
 {
     if (!mismatches)

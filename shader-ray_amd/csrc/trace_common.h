@@ -228,6 +228,11 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
 {
     const unsigned int patch = blockIdx.x;
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#ifdef SHRAY_DIAGNOSTICS
+    // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a
+    // buffer nothing else reads
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
     const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
 
@@ -277,6 +282,19 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
     if (store)
         out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
 
+#ifdef SHRAY_DIAGNOSTICS
+    if (COUNT && lane == 0) {
+        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + 1) + 4ull * (blockIdx.x * 4u + wave);
+        unsigned int hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        unsigned int xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        tl[0] = t_begin;
+        tl[1] = __builtin_amdgcn_s_memrealtime();
+        tl[2] = ((unsigned long long)xcc_id << 32) | hw_id;
+        tl[3] = rc.node_visits;
+    }
+#endif
     if (COUNT) {
         const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
                                       rc.env_lookups, rc.traversals, rc.bad_hits};

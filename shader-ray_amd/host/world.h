@@ -57,6 +57,7 @@ world_ptr load_world(const std::string &filename);
 // installed with set_trace_environment(); `image` receives width*height RGB8,
 // top row first.  Implemented in tools/trace_image.cpp (needs the HIP library).
 void trace_image(int width, int height, float aspect, unsigned char *image, const world_ptr Wd, const vec3 &light_dir);
+void set_trace_environment(const float *rgb, int width, int height);   // [height][width][3], row 0 = straight down
 
 // The arrays the fragment shader samples, exactly as the reference lays them
 // out (world.h:68-93, world.cpp:298-347).  All float32; every array is padded

@@ -1,0 +1,94 @@
+"""World-size-2 (and 3) rehearsal of the multi-GPU frame split on CPU with the gloo backend.
+
+The real path renders each rank's interleaved tiles with the HIP kernel and gathers the
+packed tile buffers to rank 0 over RCCL (shader-ray_amd/multigpu.py).  Here the same
+gather + de-interleave code runs under gloo, with the CPU oracle standing in for the
+renderer of a rank's tiles (this is a test: the product path itself has no CPU fallback),
+and the assembled frame must equal a single full-frame oracle render bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, TILE = 88, 56, 16      # 6 x 4 tiles, the right and top edges are partial
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, out_path):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    import helpers
+    import oracle
+    pkg = load_package()
+    from shader_ray_amd import multigpu
+
+    scene_world = pkg.World(helpers.small_trisrc())
+    desc = scene_world.flatten()
+    env = pkg.scenes.environment_hdr_sky(64)
+    params = scene_world.frame_params(W, H, material=6)
+
+    def render_tiles(tile_set, out):
+        # stand-in for Scene.render_into: fill this rank's packed tile buffer from the oracle
+        full, _ = oracle.render(desc, env, params, W, H, 1, threads=2)
+        tiles, tiles_x, _ = multigpu.owned_tiles(W, H, tile_set.tile_w, tile_set.tile_h, tile_set.tile_stride, tile_set.tile_phase)
+        packed = out.view(-1, tile_set.tile_h, tile_set.tile_w, 4)
+        for k, t in enumerate(tiles):
+            x0, y0 = (t % tiles_x) * tile_set.tile_w, (t // tiles_x) * tile_set.tile_h
+            w, h = min(tile_set.tile_w, W - x0), min(tile_set.tile_h, H - y0)
+            packed[k, :h, :w] = torch.from_numpy(full[y0:y0 + h, x0:x0 + w])
+
+    frame = multigpu.render_frame_distributed(render_tiles, W, H, TILE, TILE, device="cpu")
+    if rank == 0:
+        want, _ = oracle.render(desc, env, params, W, H, 1, threads=2)
+        np.save(out_path, np.stack([frame.numpy(), want]))
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiles_gather_and_reassemble(world, tmp_path, pkg, oracle_mod):
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(worker, args=(world, free_port(), out), nprocs=world, join=True)
+    got, want = np.load(out)
+    assert got.shape == (H, W, 4)
+    assert np.array_equal(got, want)
+
+
+def test_tile_ownership_covers_the_frame_once(pkg):
+    from shader_ray_amd import multigpu
+    for (w, h, tw, th, world) in ((1920, 1080, 32, 32, 8), (3840, 2160, 32, 32, 8), (100, 70, 16, 32, 3), (16, 16, 16, 16, 4)):
+        seen = []
+        for r in range(world):
+            tiles, tx, ty = multigpu.owned_tiles(w, h, tw, th, world, r)
+            assert len(tiles) <= multigpu.max_tiles_per_rank(w, h, tw, th, world)
+            seen += tiles
+        assert sorted(seen) == list(range(tx * ty))
+    # the 8-way split of a 1080p frame is balanced to within one tile
+    counts = [len(multigpu.owned_tiles(1920, 1080, 32, 32, 8, r)[0]) for r in range(8)]
+    assert max(counts) - min(counts) <= 1
+
+
+def test_assemble_torch_matches_numpy(pkg):
+    from shader_ray_amd import multigpu
+    rng = np.random.default_rng(3)
+    w, h, tw, th, world = 100, 70, 16, 32, 3
+    per = multigpu.max_tiles_per_rank(w, h, tw, th, world)
+    parts = [rng.random((per, th, tw, 4), dtype=np.float32) for _ in range(world)]
+    a = multigpu.assemble_tiles([p.reshape(-1) for p in parts], w, h, tw, th)
+    b = multigpu.assemble_tiles_torch(torch.from_numpy(np.stack(parts)), w, h, tw, th).numpy()
+    assert np.array_equal(a, b)

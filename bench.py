@@ -145,7 +145,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
                                    "2048x1024 HDR sky, 1920x1080, 1 spp, gold, 3 bounces (BASELINE configs[1])",
-                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": "stack" if args.kernel == 0 else "threaded",
+                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "persistent"}[args.kernel],
                        "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu"},
         }
     if not distributed:

@@ -99,7 +99,8 @@ struct DeviceBuffer {
 
 struct shray_scene {
     int device = 0;
-    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel
+    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel, 2 = persistent kernel
+    int resident_blocks = 1024; // persistent kernel grid: CUs x resident workgroups per CU
     bool packed_ok = false;     // link tables verified against the packed tree
     int stack_levels = 1;
 
@@ -107,6 +108,7 @@ struct shray_scene {
     DeviceBuffer packed_nodes, packed_tris;
     DeviceBuffer env;
     DeviceBuffer counters;
+    DeviceBuffer work_counter;
 
     SceneView view{};
 };
@@ -351,7 +353,10 @@ int launch(shray_scene *s, const FrameView &fr, float4 *d_out, DeviceCounters *d
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
-    if (s->kernel_id == 0 && s->packed_ok)
+    if (s->kernel_id == 2 && s->packed_ok)
+        e = launch_persistent(s->view, fr, d_out, d_counters, stream, s->stack_levels,
+                              (unsigned int *)s->work_counter.p, s->resident_blocks);
+    else if (s->kernel_id == 0 && s->packed_ok)
         e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else
         e = launch_threaded(s->view, fr, d_out, d_counters, stream);
@@ -449,6 +454,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     HIP_TRY(s->objects.upload(desc->group_objects, ng * 8));
     HIP_TRY(s->hitmiss.upload(desc->group_hitmiss, (size_t)stride * 8 * 8));
     HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters)));
+    HIP_TRY(s->work_counter.upload(nullptr, sizeof(unsigned int)));
 
     // packed layout for the stack kernel, if the tables describe a canonical threaded tree
     int depth = 0;
@@ -486,6 +492,9 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         s->view.exact_div_ok = coords_ok ? 1u : 0u;
         s->stack_levels = std::max(1, depth);
         s->packed_ok = true;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        s->resident_blocks = std::max(1, prop.multiProcessorCount) * persistent_blocks_per_cu(s->stack_levels);
     }
 
     SceneView &v = s->view;
@@ -532,9 +541,9 @@ int shray_scene_destroy(shray_scene *scene)
 
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
-    if (!scene || kernel_id < 0 || kernel_id > 1)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded)", kernel_id);
-    if (kernel_id == 0 && !scene->packed_ok)
+    if (!scene || kernel_id < 0 || kernel_id > 2)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = persistent)", kernel_id);
+    if (kernel_id != 1 && !scene->packed_ok)
         return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
                     "literal threaded kernel (1) can run it");
     scene->kernel_id = kernel_id;

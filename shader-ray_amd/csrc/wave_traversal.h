@@ -1,0 +1,203 @@
+// wave_traversal.h -- the BVH walk as two wave-cooperative stages over per-lane state.
+//
+// A lane's traversal is a strictly sequential program (raytracer.es.fs:386-443): visit a
+// node, if it is a leaf whose box is hit test its triangles in order, then follow the hit /
+// miss link.  Inside a wave, lanes reach their leaves at different times; if each lane runs
+// its <= 10 dependent triangle tests the moment it arrives, the other 63 lanes wait for it
+// on almost every iteration (measured: the frame lasted as long as its most divergent wave,
+// profiles/r01).  Here every lane keeps its own order, but the WAVE decides which kind of
+// step to run next:
+//
+//   inner_stage   lanes in WALK visit one node each (slab test, push far child / pop, the
+//                 iteration-cap bookkeeping); a lane whose leaf box is hit parks in LEAF
+//   leaf_stage    all parked lanes run their triangle loops together, then move on
+//
+// The node loop keeps running while enough lanes are still walking (kKeepWalking) and hands
+// over to the leaf stage once most lanes are parked, so triangle tests run with many lanes
+// active instead of one or two.  Used by kernel_stack.hip (one traversal per lane at a time)
+// and kernel_persistent.hip (lanes also in FETCH / SHADE states).
+//
+// Arithmetic, visit order and iteration counting are exactly those of stack_traversal.h's
+// first version and of the literal threaded kernel; tests require bit-identical frames and
+// equal work counters across all of them.
+#pragma once
+
+#include "exact_div.h"
+#include "packed_layout.h"
+#include "trace_common.h"
+
+namespace shray {
+
+enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with the persistent kernel's phases
+
+struct LaneTraversal {
+    V3 P, D, Y;               // object-space ray, reciprocal direction
+    bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
+    uint32_t positive_dir;
+    Hit hit;
+    uint32_t node;
+    int sp, iter;
+    float leaf_r0, leaf_r1;
+    uint32_t leaf_first, leaf_count;
+};
+
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
+template <bool COUNT>
+__device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t, V3 P, V3 D, RayCounters &rc)
+{
+    t.P = P;
+    t.D = D;
+    t.divide = !(sc.exact_div_ok && divisor_in_range(D.x) && divisor_in_range(D.y) && divisor_in_range(D.z) &&
+                 coordinate_in_range(P.x) && coordinate_in_range(P.y) && coordinate_in_range(P.z));
+    t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    t.fx = D.x >= 0.0f;
+    t.fy = D.y >= 0.0f;
+    t.fz = D.z >= 0.0f;
+    t.positive_dir = (D.x > 0.0f ? 1u : 0u) | (D.y > 0.0f ? 2u : 0u) | (D.z > 0.0f ? 4u : 0u);
+    t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
+    t.node = sc.packed_root;
+    t.sp = 0;
+    t.iter = 0;
+    if (COUNT)
+        rc.traversals++;
+}
+
+// A node visit (with its triangles, if any) is over: follow the link and apply the
+// iteration cap (fs:426-438).  Returns the lane's next state.
+template <int BLOCK>
+__device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, int max_iterations, bool descended,
+                                            uint32_t near_child)
+{
+    bool finished = false;
+    if (descended) {
+        t.node = near_child;
+    } else if (t.sp == 0) {
+        finished = true;
+    } else {
+        t.sp--;
+        t.node = stack[t.sp * BLOCK];
+    }
+    if (!finished && t.iter == max_iterations - 1) {
+        t.hit.t = -1.0f;   // set_bad_hit
+        finished = true;
+    }
+    t.iter++;
+    return finished ? LT_ENDED : LT_WALK;
+}
+
+// One node visit for a lane in LT_WALK; returns its next state.
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack,
+                                          RayCounters &rc)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
+    if (COUNT)
+        rc.node_visits++;
+    const float4 lo = nodes[2u * t.node];
+    const float4 hi = nodes[2u * t.node + 1u];
+    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
+    if (COUNT && (b & kLeafFlag))
+        rc.leaf_visits++;   // the reference fetches (start, count) before the box test, fs:263-267
+
+    // range_intersect_box against [0, 1e8] (fs:200-217): the entry plane is the box's low
+    // side when D >= 0, else its high side
+    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
+    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
+    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant(ex, t.D.x, t.Y.x)), div_by_constant(ey, t.D.y, t.Y.y)),
+                     div_by_constant(ez, t.D.z, t.Y.z));
+    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant(xx, t.D.x, t.Y.x)), div_by_constant(xy, t.D.y, t.Y.y)),
+                     div_by_constant(xz, t.D.z, t.Y.z));
+    if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
+        r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
+        r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
+    }
+
+    if (!(r0 >= r1) && (r0 < t.hit.t)) {
+        if (b & kLeafFlag) {
+            const uint32_t count = min(b & ~kLeafFlag, (uint32_t)fr.max_leaf_tests);
+            if (count > 0) {
+                t.leaf_first = a;
+                t.leaf_count = count;
+                t.leaf_r0 = r0;
+                t.leaf_r1 = r1;
+                return LT_LEAF;
+            }
+            return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+        }
+        const uint32_t axis = a >> 30;
+        const uint32_t pos_child = a & kChildMask, neg_child = b;
+        const bool neg_first = (t.positive_dir >> axis) & 1u;
+        stack[t.sp * BLOCK] = neg_first ? pos_child : neg_child;
+        t.sp++;
+        return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, true, neg_first ? neg_child : pos_child);
+    }
+    return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+}
+
+// triangle_intersect (fs:297-346) of triangle `which` for a parked lane
+template <bool COUNT>
+__device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc)
+{
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.packed_tris);
+    if (COUNT)
+        rc.triangle_tests++;
+    const float4 q0 = tris[3u * which], q1 = tris[3u * which + 1u], q2 = tris[3u * which + 2u];
+    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
+    const V3 M = cross3(e1, t.D);
+    const float det = dot3(e0, M);
+    if (det > -0.0000001f && det < 0.0000001f)
+        return;
+    const float inv_det = 1.0f / det;
+    const V3 T = t.P - v0;
+    const V3 Q = cross3(T, e0);
+    const float dist = -dot3(e1, Q) * inv_det;
+    if (dist > t.hit.t || dist < t.leaf_r0 || dist > t.leaf_r1)
+        return;
+    const float u = dot3(T, M) * inv_det;
+    if (u < 0.0f || u > 1.0f)
+        return;
+    const float w = dot3(t.D, Q) * inv_det;
+    if (w < 0.0f || u + w > 1.0f)
+        return;
+    t.hit.which = (float)which;
+    t.hit.t = dist;
+    t.hit.bu = u;
+    t.hit.bv = w;
+}
+
+// Node loop: lanes whose state is LT_WALK visit nodes until fewer than `keep_walking` of
+// them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting)
+{
+    for (;;) {
+        if (!wave_ballot(state == LT_WALK))
+            return;
+        if (state == LT_WALK)
+            state = lane_visit<COUNT, BLOCK>(sc, fr, t, stack, rc);
+        const int walking = __popcll(wave_ballot(state == LT_WALK));
+        if (walking < keep_walking && (wave_ballot(state == LT_LEAF) || others_waiting))
+            return;
+    }
+}
+
+// Leaf stage: every parked lane tests its leaf's triangles in order, then follows its link.
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                           uint32_t *stack, RayCounters &rc)
+{
+    if (!wave_ballot(state == LT_LEAF))
+        return;
+    for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
+        if (state == LT_LEAF && j < t.leaf_count)
+            lane_test_triangle<COUNT>(sc, t, t.leaf_first + j, rc);
+    }
+    if (state == LT_LEAF)
+        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+}
+
+}   // namespace shray

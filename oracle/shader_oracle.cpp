@@ -178,6 +178,9 @@ struct Ctx {
     Counters c;
 };
 
+// optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
+uint32_t *g_visit_map = nullptr;
+
 struct ray {   // fs:58-63 (differentials only matter for which in {1,2,3}; not carried here)
     vec3 P, D;
 };
@@ -492,6 +495,7 @@ void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float 
 {
     const shray_frame_params &p = *cx.p;
     vec3 sum = V(0, 0, 0);
+    const uint64_t visits_before = cx.c.node_visits + (cx.c.triangle_tests << 32);
     for (int s = 0; s < spp; s++) {
         const float ox = ((float)s + 0.5f) / (float)spp;
         const float oy = (float)bitreverse32((uint32_t)s) * 2.3283064365386963e-10f + 0.5f / (float)spp;
@@ -507,6 +511,14 @@ void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float 
     out[1] = result.y;
     out[2] = result.z;
     out[3] = 1.0f;
+    if (g_visit_map)
+    {
+        const uint64_t now = cx.c.node_visits + (cx.c.triangle_tests << 32), delta = now - visits_before;
+        // low 16 bits: node visits, high 16 bits: triangle tests (both saturating)
+        const uint32_t nv = (uint32_t)std::min<uint64_t>(delta & 0xffffffffu, 0xffffu);
+        const uint32_t tt = (uint32_t)std::min<uint64_t>(delta >> 32, 0xffffu);
+        g_visit_map[(size_t)py * width + px] = nv | (tt << 16);
+    }
 }
 
 }   // namespace
@@ -582,6 +594,9 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
     }
     return 0;
 }
+
+// Diagnostics: when set, shray_oracle_render also writes node visits per pixel (width*height uint32).
+void shray_oracle_set_visit_map(uint32_t *map) { g_visit_map = map; }
 
 // Pieces exposed for the known-answer tests.
 float shray_oracle_filmic(float c) { return filmic(c); }

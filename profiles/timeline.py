@@ -38,8 +38,26 @@ def main():
     W, H = args.width, args.height
     params = world.frame_params(W, H, material=args.material)
     patches = ((W + 15) // 16) * ((H + 15) // 16)
-    stamps = np.zeros((patches * 4, 4), dtype=np.uint64)
+    stamps = np.zeros((patches * 4, 8), dtype=np.uint64)
     N.check(lib.shray_debug_timeline(scene._handle, C.byref(params), W, H, 1, stamps.ctypes.data_as(C.c_void_p)))
+    if args.kernel == 2:
+        raw = stamps.reshape(-1)
+        rows = raw[: (len(raw) // 16) * 16].reshape(-1, 16)
+        rows = rows[rows[:, 1] > 0]
+        t0 = rows[:, 0].astype(np.float64)
+        t1 = rows[:, 1].astype(np.float64)
+        span = (t1.max() - t0.min()) * 10e-3
+        dur = (t1 - t0) * 10e-3
+        print(f"persistent kernel: span {span:.1f} us, {len(rows)} waves; wave life us min {dur.min():.1f} p50 {np.median(dur):.1f} max {dur.max():.1f}")
+        tot = rows[:, 2:10].astype(np.float64).sum(axis=0)
+        names = ["outer iterations", "fetch passes", "shade passes", "node-loop iterations", "leaf-loop iterations",
+                 "cycles in fetch", "cycles in walk (node+leaf)", "cycles in shade"]
+        for n, v in zip(names, tot):
+            print(f"  {n:28s} {v:.4g}")
+        print(f"  per node+leaf iteration: {tot[6] / (tot[3] + tot[4]):.0f} cycles; per fetch pass {tot[5] / tot[1]:.0f}; per shade pass {tot[7] / tot[2]:.0f}")
+        ends = np.sort(t1 - t0.min()) * 10e-3
+        print("  wave end times us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(ends, [10, 50, 90, 99, 100])))
+        return
     t0 = stamps[:, 0].astype(np.float64)
     t1 = stamps[:, 1].astype(np.float64)
     hw = (stamps[:, 2] & np.uint64(0xffffffff)).astype(np.uint32)
@@ -70,8 +88,12 @@ def main():
     px = ((W + 15) // 16)
     for i in order:
         blk = i // 4
-        print(f"heavy wave: block ({blk % px},{blk // px}) wave {i % 4} dur {dur[i]:.1f} us start +{(t0[i] - start) * 10e-3:.1f} us "
-              f"lane0 node visits {int(stamps[i, 3])}")
+        ni, li, nc, lc = (int(v) for v in stamps[i, 4:8])
+        print(f"heavy wave: block ({blk % px},{blk // px}) wave {i % 4} dur {dur[i]:.1f} us start +{(t0[i] - start) * 10e-3:.1f} us; "
+              f"node loop {ni} iterations x {nc / max(ni, 1):.0f} cycles, leaf loop {li} iterations x {lc / max(li, 1):.0f} cycles, "
+              f"in loops {(nc + lc) / 2.4e3:.0f} us at 2.4 GHz")
+    tot = stamps[:, 4:8].astype(np.float64).sum(axis=0)
+    print(f"all waves: node loop {tot[0]:.3g} iterations x {tot[2] / tot[0]:.0f} cycles; leaf loop {tot[1]:.3g} iterations x {tot[3] / max(tot[1], 1):.0f} cycles")
     busy = {}
     for k, d in zip(cu_key, dur):
         busy[k] = busy.get(k, 0.0) + d

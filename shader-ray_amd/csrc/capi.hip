@@ -453,7 +453,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     HIP_TRY(s->boxmax.upload(desc->group_boxmax, ng * 12));
     HIP_TRY(s->objects.upload(desc->group_objects, ng * 8));
     HIP_TRY(s->hitmiss.upload(desc->group_hitmiss, (size_t)stride * 8 * 8));
-    HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters)));
+    HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters) * kCounterShards));
     HIP_TRY(s->work_counter.upload(nullptr, sizeof(unsigned int)));
 
     // packed layout for the stack kernel, if the tables describe a canonical threaded tree
@@ -618,13 +618,23 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
     DeviceBuffer frame;
     const size_t bytes = (size_t)width * height * 16;
     HIP_TRY(frame.upload(nullptr, bytes));
-    HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(DeviceCounters)));
+    HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(DeviceCounters) * kCounterShards));
     rc = launch(scene, fr, (float4 *)frame.p, (DeviceCounters *)scene->counters.p, nullptr);
     if (rc)
         return rc;
     HIP_TRY(hipDeviceSynchronize());
-    DeviceCounters dc;
-    HIP_TRY(hipMemcpy(&dc, scene->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    DeviceCounters shards[kCounterShards];
+    HIP_TRY(hipMemcpy(shards, scene->counters.p, sizeof(shards), hipMemcpyDeviceToHost));
+    DeviceCounters dc = {};
+    for (const DeviceCounters &sh : shards) {
+        dc.node_visits += sh.node_visits;
+        dc.leaf_visits += sh.leaf_visits;
+        dc.triangle_tests += sh.triangle_tests;
+        dc.shaded_hits += sh.shaded_hits;
+        dc.env_lookups += sh.env_lookups;
+        dc.traversals += sh.traversals;
+        dc.bad_hits += sh.bad_hits;
+    }
     if (rgba_out_host)
         HIP_TRY(hipMemcpy(rgba_out_host, frame.p, bytes, hipMemcpyDeviceToHost));
     counters->node_visits = dc.node_visits;
@@ -640,8 +650,10 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
 
 #ifdef SHRAY_DIAGNOSTICS
 // Diagnostic build only (libshray_hip_diag.so, profiles/timeline.py): renders one frame with
-// the counting kernel and returns 4 x uint64 per wave {begin, end (100 MHz ticks), xcc<<32|hw_id,
-// lane-0 node visits}; `stamps` must hold 16 * ceil(w/16) * ceil(h/16) values.
+// the timed kernel and returns per wave 8 x uint64 {begin, end (100 MHz ticks), xcc<<32|hw_id, 0,
+// node-loop iterations, leaf-loop iterations, cycles in the node loop, cycles in the leaf loop}
+// (stack kernel) or 16 x uint64 (persistent kernel, see kernel_persistent.hip);
+// `stamps` must hold 32 * ceil(w/16) * ceil(h/16) values.
 int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
                          uint64_t *stamps)
 {
@@ -652,17 +664,19 @@ int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, i
     rc = make_frame_view(params, width, height, spp, nullptr, &fr);
     if (rc)
         return rc;
-    const size_t nstamps = (size_t)fr.total_patches * 16;
+    const size_t nstamps = (size_t)fr.total_patches * 32;
     DeviceBuffer frame, dbg;
     HIP_TRY(frame.upload(nullptr, (size_t)width * height * 16));
-    HIP_TRY(dbg.upload(nullptr, sizeof(DeviceCounters) + nstamps * 8));
+    HIP_TRY(dbg.upload(nullptr, sizeof(DeviceCounters) * kCounterShards + nstamps * 8));
+    shray::g_diag_plain_kernel = true;   // stamp the timed (non-counting) kernel
     for (int rep = 0; rep < 3; rep++) {   // warm caches; the last run's stamps are returned
         rc = launch(scene, fr, (float4 *)frame.p, (DeviceCounters *)dbg.p, nullptr);
         if (rc)
             return rc;
         HIP_TRY(hipDeviceSynchronize());
     }
-    HIP_TRY(hipMemcpy(stamps, (char *)dbg.p + sizeof(DeviceCounters), nstamps * 8, hipMemcpyDeviceToHost));
+    shray::g_diag_plain_kernel = false;
+    HIP_TRY(hipMemcpy(stamps, (char *)dbg.p + sizeof(DeviceCounters) * kCounterShards, nstamps * 8, hipMemcpyDeviceToHost));
     return SHRAY_OK;
 }
 #endif

@@ -69,5 +69,8 @@ struct FrameView {
 struct DeviceCounters {
     unsigned long long node_visits, leaf_visits, triangle_tests, shaded_hits, env_lookups, traversals, bad_hits, samples;
 };
+// The counting kernels add into kCounterShards copies (shard = workgroup index mod
+// kCounterShards) so that thousands of waves do not serialise on seven addresses; the host sums.
+constexpr int kCounterShards = 64;
 
 }   // namespace shray

@@ -52,6 +52,10 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
     extern __shared__ uint32_t lds_stack[];
     uint32_t *const stack = lds_stack + threadIdx.x;   // [level * kPBlock]
     const unsigned int lane = threadIdx.x & 63u;
+#ifdef SHRAY_DIAGNOSTICS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long diag_outer = 0, diag_fetch = 0, diag_shade = 0, diag_c_fetch = 0, diag_c_shade = 0, diag_c_walk = 0;
+#endif
 
     const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);
     const V3 spec = mk(fr.specular_color[0], fr.specular_color[1], fr.specular_color[2]);
@@ -81,6 +85,7 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
     t.iter = 0;
     t.leaf_count = 0;
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
+    SHRAY_DIAG_DECL
 
     // start a traversal of the object-space image of (origin, direction)       (fs:489-491, :462-463)
     auto begin_traversal = [&](V3 origin, V3 direction) {
@@ -89,11 +94,18 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
     };
 
     for (;;) {
+#ifdef SHRAY_DIAGNOSTICS
+        diag_outer++;
+        const unsigned long long dc0 = __builtin_amdgcn_s_memtime();
+#endif
         // ------------------------------------------------------------------ FETCH
         {
             const unsigned long long want = ballot(phase == PH_FETCH);
             const unsigned long long busy = ballot(phase == PH_INNER || phase == PH_LEAF || phase == PH_SHADE);
             if (want && (popc64(want) >= kFetchMin || !busy)) {
+#ifdef SHRAY_DIAGNOSTICS
+                diag_fetch++;
+#endif
                 bool need = phase == PH_FETCH;
                 // next sample of the same pixel?
                 bool new_pixel = need && !(have_pixel && sample < fr.spp);
@@ -187,15 +199,24 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
         if (ballot(phase != PH_DONE) == 0ull)
             break;
 
+#ifdef SHRAY_DIAGNOSTICS
+        const unsigned long long dc1 = __builtin_amdgcn_s_memtime();
+#endif
         // ------------------------------------------------------------------ INNER + LEAF (wave_traversal.h)
-        inner_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc, kInnerKeep, wave_ballot(phase == PH_SHADE) != 0ull);
-        leaf_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc);
+        inner_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc, kInnerKeep, wave_ballot(phase == PH_SHADE) != 0ull SHRAY_DIAG_ARG);
+        leaf_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc SHRAY_DIAG_ARG);
+#ifdef SHRAY_DIAGNOSTICS
+        const unsigned long long dc2 = __builtin_amdgcn_s_memtime();
+#endif
 
         // ------------------------------------------------------------------ SHADE
         {
             const unsigned long long ended = ballot(phase == PH_SHADE);
             const unsigned long long walking = ballot(phase == PH_INNER || phase == PH_LEAF);
             if (ended && (popc64(ended) >= kShadeMin || !walking)) {
+#ifdef SHRAY_DIAGNOSTICS
+                diag_shade++;
+#endif
                 if (phase == PH_SHADE) {
                     bool path_done = false;
                     bool next_bounce = false;
@@ -290,12 +311,34 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
                 }
             }
         }
+#ifdef SHRAY_DIAGNOSTICS
+        const unsigned long long dc3 = __builtin_amdgcn_s_memtime();
+        diag_c_fetch += dc1 - dc0;
+        diag_c_walk += dc2 - dc1;
+        diag_c_shade += dc3 - dc2;
+#endif
     }
+
+#ifdef SHRAY_DIAGNOSTICS
+    if (counters && lane == 0) {   // diagnostic build: per-wave life stamps and stage tallies (profiles/timeline.py)
+        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        tl[0] = t_begin;
+        tl[1] = __builtin_amdgcn_s_memrealtime();
+        tl[2] = diag_outer;
+        tl[3] = diag_fetch;
+        tl[4] = diag_shade;
+        tl[5] = diag_tally[0];
+        tl[6] = diag_tally[1];
+        tl[7] = diag_c_fetch;
+        tl[8] = diag_c_walk;
+        tl[9] = diag_c_shade;
+    }
+#endif
 
     if (COUNT) {
         const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
                                       rc.env_lookups, rc.traversals, rc.bad_hits};
-        unsigned long long *dst = &counters->node_visits;
+        unsigned long long *dst = &counters[blockIdx.x % kCounterShards].node_visits;
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const unsigned long long s = wave_sum(vals[k]);
@@ -323,6 +366,12 @@ hipError_t launch_persistent(const SceneView &sc, const FrameView &fr, float4 *o
     const unsigned int blocks = (unsigned int)resident_blocks < fr.total_patches ? (unsigned int)resident_blocks : fr.total_patches;
     const dim3 grid(blocks), block(kPBlock);
     const size_t lds_bytes = (size_t)kPBlock * (size_t)stack_levels * sizeof(uint32_t);
+#ifdef SHRAY_DIAGNOSTICS
+    if (counters && g_diag_plain_kernel) {
+        hipLaunchKernelGGL(trace_persistent_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters, work_counter);
+        return hipGetLastError();
+    }
+#endif
     if (counters)
         hipLaunchKernelGGL(trace_persistent_kernel<true>, grid, block, lds_bytes, stream, sc, fr, out, counters, work_counter);
     else

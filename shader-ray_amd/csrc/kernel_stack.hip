@@ -10,6 +10,9 @@
 namespace shray {
 
 constexpr int kBlock = 256;
+#ifdef SHRAY_DIAGNOSTICS
+bool g_diag_plain_kernel = false;
+#endif
 
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
@@ -25,6 +28,12 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 {
     const dim3 grid(fr.total_patches), block(kBlock);
     const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t);
+#ifdef SHRAY_DIAGNOSTICS
+    if (counters && g_diag_plain_kernel) {
+        hipLaunchKernelGGL(trace_stack_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+        return hipGetLastError();
+    }
+#endif
     if (counters)
         hipLaunchKernelGGL(trace_stack_kernel<true>, grid, block, lds_bytes, stream, sc, fr, out, counters);
     else

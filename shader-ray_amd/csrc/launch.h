@@ -7,6 +7,10 @@
 
 namespace shray {
 
+#ifdef SHRAY_DIAGNOSTICS
+extern bool g_diag_plain_kernel;   // diagnostic build: run the non-counting kernel even with a counters buffer
+#endif
+
 // counters == nullptr selects the plain (timed) kernel, otherwise the counting variant.
 hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
                            hipStream_t stream);

@@ -25,6 +25,9 @@ constexpr int kStackKeepWalking = 24;
 template <int BLOCK>
 struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
+#ifdef SHRAY_DIAGNOSTICS
+    unsigned long long diag_tally[4] = {0, 0, 0, 0};
+#endif
 
     template <bool COUNT>
     __device__ __forceinline__ void closest(const SceneView &sc, const FrameView &fr, V3 P, V3 D, Hit &hit,
@@ -34,8 +37,19 @@ struct StackTraversal {
         lane_begin<COUNT>(sc, t, P, D, rc);
         int state = LT_WALK;
         do {
-            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false);
-            leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc);
+#ifdef SHRAY_DIAGNOSTICS
+            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
+            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
+#ifdef SHRAY_DIAGNOSTICS
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
+            leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
+#ifdef SHRAY_DIAGNOSTICS
+            const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+            diag_tally[2] += c1 - c0;
+            diag_tally[3] += c2 - c1;
+#endif
         } while (wave_ballot(state != LT_ENDED));
         hit = t.hit;
     }

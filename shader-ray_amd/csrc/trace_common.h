@@ -283,8 +283,8 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
         out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
 
 #ifdef SHRAY_DIAGNOSTICS
-    if (COUNT && lane == 0) {
-        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + 1) + 4ull * (blockIdx.x * 4u + wave);
+    if (counters && lane == 0) {
+        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 8ull * (blockIdx.x * 4u + wave);
         unsigned int hw_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         unsigned int xcc_id;
@@ -293,12 +293,14 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
         tl[1] = __builtin_amdgcn_s_memrealtime();
         tl[2] = ((unsigned long long)xcc_id << 32) | hw_id;
         tl[3] = rc.node_visits;
+        for (int k = 0; k < 4; k++)
+            tl[4 + k] = trav.diag_tally[k];
     }
 #endif
     if (COUNT) {
         const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
                                       rc.env_lookups, rc.traversals, rc.bad_hits};
-        unsigned long long *dst = &counters->node_visits;
+        unsigned long long *dst = &counters[blockIdx.x % kCounterShards].node_visits;
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const unsigned long long s = wave_sum(vals[k]);

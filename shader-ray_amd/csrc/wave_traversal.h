@@ -30,6 +30,20 @@ namespace shray {
 
 enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with the persistent kernel's phases
 
+// Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
+// cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
+#ifdef SHRAY_DIAGNOSTICS
+#define SHRAY_DIAG_DECL unsigned long long diag_tally[4] = {0, 0, 0, 0};
+#define SHRAY_DIAG_COUNT(k) (diag_tally_ref[k]++)
+#define SHRAY_DIAG_PARAM , unsigned long long *diag_tally_ref
+#define SHRAY_DIAG_ARG , diag_tally
+#else
+#define SHRAY_DIAG_DECL
+#define SHRAY_DIAG_COUNT(k) ((void)0)
+#define SHRAY_DIAG_PARAM
+#define SHRAY_DIAG_ARG
+#endif
+
 struct LaneTraversal {
     V3 P, D, Y;               // object-space ray, reciprocal direction
     bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
@@ -172,11 +186,12 @@ __device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTrav
 // them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting)
+                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM)
 {
     for (;;) {
         if (!wave_ballot(state == LT_WALK))
             return;
+        SHRAY_DIAG_COUNT(0);
         if (state == LT_WALK)
             state = lane_visit<COUNT, BLOCK>(sc, fr, t, stack, rc);
         const int walking = __popcll(wave_ballot(state == LT_WALK));
@@ -188,11 +203,12 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
 // Leaf stage: every parked lane tests its leaf's triangles in order, then follows its link.
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                           uint32_t *stack, RayCounters &rc)
+                                           uint32_t *stack, RayCounters &rc SHRAY_DIAG_PARAM)
 {
     if (!wave_ballot(state == LT_LEAF))
         return;
     for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
+        SHRAY_DIAG_COUNT(1);
         if (state == LT_LEAF && j < t.leaf_count)
             lane_test_triangle<COUNT>(sc, t, t.leaf_first + j, rc);
     }

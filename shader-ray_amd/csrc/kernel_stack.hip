@@ -14,8 +14,16 @@ constexpr int kBlock = 256;
 bool g_diag_plain_kernel = false;
 #endif
 
+// tuning hooks (experiments: make HIP_EXTRA='-DSHRAY_MIN_WAVES=5 -DSHRAY_LDS_PAD=32768')
+#ifndef SHRAY_MIN_WAVES
+#define SHRAY_MIN_WAVES 1
+#endif
+#ifndef SHRAY_LDS_PAD
+#define SHRAY_LDS_PAD 0
+#endif
+
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
 {
     extern __shared__ uint32_t lds_stack[];
     StackTraversal<kBlock> trav;
@@ -27,7 +35,7 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
                         hipStream_t stream, int stack_levels)
 {
     const dim3 grid(fr.total_patches), block(kBlock);
-    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t);
+    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + SHRAY_LDS_PAD;
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && g_diag_plain_kernel) {
         hipLaunchKernelGGL(trace_stack_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters);

@@ -38,7 +38,7 @@ def main():
     W, H = args.width, args.height
     params = world.frame_params(W, H, material=args.material)
     patches = ((W + 15) // 16) * ((H + 15) // 16)
-    stamps = np.zeros((patches * 4, 8), dtype=np.uint64)
+    stamps = np.zeros((patches * 4, 16), dtype=np.uint64)
     N.check(lib.shray_debug_timeline(scene._handle, C.byref(params), W, H, 1, stamps.ctypes.data_as(C.c_void_p)))
     if args.kernel == 2:
         raw = stamps.reshape(-1)
@@ -91,9 +91,11 @@ def main():
         ni, li, nc, lc = (int(v) for v in stamps[i, 4:8])
         print(f"heavy wave: block ({blk % px},{blk // px}) wave {i % 4} dur {dur[i]:.1f} us start +{(t0[i] - start) * 10e-3:.1f} us; "
               f"node loop {ni} iterations x {nc / max(ni, 1):.0f} cycles, leaf loop {li} iterations x {lc / max(li, 1):.0f} cycles, "
-              f"in loops {(nc + lc) / 2.4e3:.0f} us at 2.4 GHz")
+              f"in loops {(nc + lc) / 2.4e3:.0f} us at 2.4 GHz; load wait per iteration: node {int(stamps[i, 8]) / max(ni, 1):.0f}, triangle {int(stamps[i, 9]) / max(li, 1):.0f} cycles")
     tot = stamps[:, 4:8].astype(np.float64).sum(axis=0)
     print(f"all waves: node loop {tot[0]:.3g} iterations x {tot[2] / tot[0]:.0f} cycles; leaf loop {tot[1]:.3g} iterations x {tot[3] / max(tot[1], 1):.0f} cycles")
+    w = stamps[:, 8:10].astype(np.float64).sum(axis=0)
+    print(f"all waves: load wait per iteration: node {w[0] / tot[0]:.0f} cycles, triangle {w[1] / max(tot[1], 1):.0f} cycles")
     busy = {}
     for k, d in zip(cu_key, dur):
         busy[k] = busy.get(k, 0.0) + d

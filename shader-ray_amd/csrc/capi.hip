@@ -653,7 +653,7 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
 // the timed kernel and returns per wave 8 x uint64 {begin, end (100 MHz ticks), xcc<<32|hw_id, 0,
 // node-loop iterations, leaf-loop iterations, cycles in the node loop, cycles in the leaf loop}
 // (stack kernel) or 16 x uint64 (persistent kernel, see kernel_persistent.hip);
-// `stamps` must hold 32 * ceil(w/16) * ceil(h/16) values.
+// `stamps` must hold 64 * ceil(w/16) * ceil(h/16) values.
 int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
                          uint64_t *stamps)
 {
@@ -664,7 +664,7 @@ int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, i
     rc = make_frame_view(params, width, height, spp, nullptr, &fr);
     if (rc)
         return rc;
-    const size_t nstamps = (size_t)fr.total_patches * 32;
+    const size_t nstamps = (size_t)fr.total_patches * 64;
     DeviceBuffer frame, dbg;
     HIP_TRY(frame.upload(nullptr, (size_t)width * height * 16));
     HIP_TRY(dbg.upload(nullptr, sizeof(DeviceCounters) * kCounterShards + nstamps * 8));

@@ -36,6 +36,19 @@ __device__ __forceinline__ float div_by_constant(float a, float b, float y)
     return __builtin_fmaf(r1, y, q1);
 }
 
+// Four-operation form with the reciprocal split in two: y = RN(1 / b) and its residual
+// yl = fma(-b, y, 1) * y  (so y + yl = 1/b to ~2^-46 relative).  a*(y + yl), evaluated as
+// fma(a, yl, a*y), is already within one ulp of a / b, which is all Markstein's final step
+// needs:   q1 = fma(a, yl, a * y);   r = fma(-b, q1, a);   q = fma(r, y, q1) == RN(a / b).
+// Same operand ranges as div_by_constant; verified by the same self-test.
+__device__ __forceinline__ float reciprocal_residual(float b, float y) { return __builtin_fmaf(-b, y, 1.0f) * y; }
+__device__ __forceinline__ float div_by_constant4(float a, float b, float y, float yl)
+{
+    const float q1 = __builtin_fmaf(a, yl, a * y);
+    const float r = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r, y, q1);
+}
+
 // exponent-field tests on the raw bits (NaN / inf fail every one of them)
 __device__ __forceinline__ bool magnitude_in(float v, int lo_exp, int hi_exp)   // 2^lo <= |v| < 2^(hi+1)
 {

@@ -34,9 +34,14 @@ enum : int { PH_FETCH = 0, PH_INNER = LT_WALK, PH_LEAF = LT_LEAF, PH_SHADE = LT_
 enum : int { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 
 // stage-switch thresholds (lanes); see DESIGN.md "Persistent kernel"
-constexpr int kFetchMin = 20;   // refill when this many lanes are idle (or nothing else can run)
-constexpr int kShadeMin = 20;   // shade when this many traversals have ended (or nothing else can run)
-constexpr int kInnerKeep = 28;  // leave the node loop when fewer lanes than this are still descending and others wait
+#ifndef SHRAY_FETCH_MIN
+#define SHRAY_FETCH_MIN 8
+#endif
+#ifndef SHRAY_SHADE_MIN
+#define SHRAY_SHADE_MIN 8
+#endif
+constexpr int kFetchMin = SHRAY_FETCH_MIN;   // refill when this many lanes are idle (or nothing else can run)
+constexpr int kShadeMin = SHRAY_SHADE_MIN;   // shade when this many traversals have ended (or nothing else can run)
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -202,9 +207,13 @@ __global__ void __launch_bounds__(kPBlock) trace_persistent_kernel(SceneView sc,
 #ifdef SHRAY_DIAGNOSTICS
         const unsigned long long dc1 = __builtin_amdgcn_s_memtime();
 #endif
-        // ------------------------------------------------------------------ INNER + LEAF (wave_traversal.h)
-        inner_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc, kInnerKeep, wave_ballot(phase == PH_SHADE) != 0ull SHRAY_DIAG_ARG);
-        leaf_stage<COUNT, kPBlock>(sc, fr, t, phase, stack, rc SHRAY_DIAG_ARG);
+        // ------------------------------------------------------------------ WALK: one node step + one triangle step
+        {
+            const unsigned long long walkers = wave_ballot(phase == PH_INNER);
+            const unsigned long long parked = wave_ballot(phase == PH_LEAF);
+            if (walkers | parked)
+                walk_step<COUNT, kPBlock>(sc, fr, t, phase, stack, rc, walkers, parked, 1 SHRAY_DIAG_ARG);
+        }
 #ifdef SHRAY_DIAGNOSTICS
         const unsigned long long dc2 = __builtin_amdgcn_s_memtime();
 #endif

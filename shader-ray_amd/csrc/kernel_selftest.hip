@@ -46,9 +46,11 @@ __global__ void __launch_bounds__(256) division_selftest_kernel(unsigned long lo
             a = b * random_in_exponent_range(mix64(h1), -3, 3, (unsigned int)(h1 >> 51));   // quotient near a "nice" value
         const float y = 1.0f / b;
         const float fast = div_by_constant(a, b, y);
+        const float fast4 = div_by_constant4(a, b, y, reciprocal_residual(b, y));
         const float exact = a / b;
         const bool same = __float_as_uint(fast) == __float_as_uint(exact) || (fast == 0.0f && exact == 0.0f);
-        bad += same ? 0ull : 1ull;
+        const bool same4 = __float_as_uint(fast4) == __float_as_uint(exact) || (fast4 == 0.0f && exact == 0.0f);
+        bad += (same && same4) ? 0ull : 1ull;
     }
     if (bad)
         atomicAdd(mismatches, bad);

@@ -38,7 +38,7 @@ template <int BLOCK>
 struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
 #ifdef SHRAY_DIAGNOSTICS
-    unsigned long long diag_tally[4] = {0, 0, 0, 0};
+    unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     template <bool COUNT>

@@ -12,7 +12,7 @@ namespace shray {
 
 struct ThreadedTraversal {
 #ifdef SHRAY_DIAGNOSTICS
-    unsigned long long diag_tally[4] = {0, 0, 0, 0};
+    unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     template <bool COUNT>
     __device__ __forceinline__ void closest(const SceneView &sc, const FrameView &fr, V3 P, V3 D, Hit &hit,

@@ -284,7 +284,7 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
 
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && lane == 0) {
-        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 8ull * (blockIdx.x * 4u + wave);
+        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 16ull * (blockIdx.x * 4u + wave);
         unsigned int hw_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         unsigned int xcc_id;
@@ -293,7 +293,7 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
         tl[1] = __builtin_amdgcn_s_memrealtime();
         tl[2] = ((unsigned long long)xcc_id << 32) | hw_id;
         tl[3] = rc.node_visits;
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 8; k++)
             tl[4 + k] = trav.diag_tally[k];
     }
 #endif

@@ -33,19 +33,25 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 // Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
 // cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
 #ifdef SHRAY_DIAGNOSTICS
-#define SHRAY_DIAG_DECL unsigned long long diag_tally[4] = {0, 0, 0, 0};
+#define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SHRAY_DIAG_T0 const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+#define SHRAY_DIAG_WAIT(k) do { __builtin_amdgcn_s_waitcnt(0); diag_tally_ref[k] += __builtin_amdgcn_s_memtime() - diag_t0; } while (0)
 #define SHRAY_DIAG_COUNT(k) (diag_tally_ref[k]++)
 #define SHRAY_DIAG_PARAM , unsigned long long *diag_tally_ref
 #define SHRAY_DIAG_ARG , diag_tally
+#define SHRAY_DIAG_ARG_FWD , diag_tally_ref
 #else
 #define SHRAY_DIAG_DECL
+#define SHRAY_DIAG_T0
+#define SHRAY_DIAG_WAIT(k) ((void)0)
 #define SHRAY_DIAG_COUNT(k) ((void)0)
 #define SHRAY_DIAG_PARAM
 #define SHRAY_DIAG_ARG
+#define SHRAY_DIAG_ARG_FWD
 #endif
 
 struct LaneTraversal {
-    V3 P, D, Y;               // object-space ray, reciprocal direction
+    V3 P, D, Y, YL;           // object-space ray, reciprocal direction RN(1/D) and its residual (exact_div.h)
     bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
     uint32_t positive_dir;
     Hit hit;
@@ -66,6 +72,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t
     t.divide = !(sc.exact_div_ok && divisor_in_range(D.x) && divisor_in_range(D.y) && divisor_in_range(D.z) &&
                  coordinate_in_range(P.x) && coordinate_in_range(P.y) && coordinate_in_range(P.z));
     t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    t.YL = mk(reciprocal_residual(D.x, t.Y.x), reciprocal_residual(D.y, t.Y.y), reciprocal_residual(D.z, t.Y.z));
     t.fx = D.x >= 0.0f;
     t.fy = D.y >= 0.0f;
     t.fz = D.z >= 0.0f;
@@ -102,6 +109,8 @@ __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, i
 }
 
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
+// (A fully predicated, branch-free form of the bookkeeping below was measured and is not faster:
+// the branches let the wave skip whole blocks with s_cbranch_execz.)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraversal &t, uint32_t *stack, RayCounters &rc,
                                                  const float4 lo, const float4 hi)
@@ -117,10 +126,10 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
     const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
     // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
-    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant(ex, t.D.x, t.Y.x)), div_by_constant(ey, t.D.y, t.Y.y)),
-                     div_by_constant(ez, t.D.z, t.Y.z));
-    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant(xx, t.D.x, t.Y.x)), div_by_constant(xy, t.D.y, t.Y.y)),
-                     div_by_constant(xz, t.D.z, t.Y.z));
+    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
+                     div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
+    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
+                     div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
     if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
         r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
         r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
@@ -189,11 +198,25 @@ __device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint
     t.hit.bv = w;
 }
 
+// The three 16-byte words of a packed triangle, fetched as three dwordx4 loads issued back to
+// back.  (Left to itself the compiler splits them into partial loads and sinks some behind the
+// `det` early-out of the test, which costs a second dependent memory round trip per triangle.)
+__device__ __forceinline__ void load_packed_triangle(const float4 *tri, float4 &q0, float4 &q1, float4 &q2)
+{
+    q0 = tri[0];
+    q1 = tri[1];
+    q2 = tri[2];
+    // pin all twelve components here: whole-word loads, nothing deferred past a branch
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                 "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc)
 {
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.packed_tris);
-    lane_test_triangle_loaded<COUNT>(t, which, rc, tris[3u * which], tris[3u * which + 1u], tris[3u * which + 2u]);
+    float4 q0, q1, q2;
+    load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * which, q0, q1, q2);
+    lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
 }
 
 // Node loop: lanes whose state is LT_WALK visit nodes until fewer than `keep_walking` of
@@ -206,8 +229,14 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
         if (!wave_ballot(state == LT_WALK))
             return;
         SHRAY_DIAG_COUNT(0);
-        if (state == LT_WALK)
-            state = lane_visit<COUNT, BLOCK>(sc, fr, t, stack, rc);
+        if (state == LT_WALK) {
+            const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
+            SHRAY_DIAG_T0
+            const float4 lo = nodes[2u * t.node];
+            const float4 hi = nodes[2u * t.node + 1u];
+            SHRAY_DIAG_WAIT(4);
+            state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+        }
         const int walking = __popcll(wave_ballot(state == LT_WALK));
         if (walking < keep_walking && (wave_ballot(state == LT_LEAF) || others_waiting))
             return;
@@ -223,58 +252,66 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
         return;
     for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
         SHRAY_DIAG_COUNT(1);
-        if (state == LT_LEAF && j < t.leaf_count)
-            lane_test_triangle<COUNT>(sc, t, t.leaf_first + j, rc);
+        if (state == LT_LEAF && j < t.leaf_count) {
+            float4 q0, q1, q2;
+            SHRAY_DIAG_T0
+            load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * (t.leaf_first + j), q0, q1, q2);
+            SHRAY_DIAG_WAIT(5);
+            lane_test_triangle_loaded<COUNT>(t, t.leaf_first + j, rc, q0, q1, q2);
+        }
     }
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
 }
 
-// Unified loop (used by kernel_stack.hip): in every iteration each walking lane visits ONE
-// node and -- when at least `min_parked` lanes are parked in a leaf, or nobody is walking --
-// each parked lane tests ONE triangle of its leaf.  Both kinds of loads are issued together at
-// the top of the iteration, so a wave pays one memory round trip per iteration whatever mix of
-// node visits and triangle tests it holds, and a lane resumes walking as soon as ITS leaf is
-// done instead of waiting for the longest leaf of the batch.  Measured on the heaviest waves
-// of the 1080p frame: ~1400 latency-exposed iterations (node loop + nested leaf loops) become
-// ~max over lanes of (visits + tests).  Per-lane order of visits and tests is unchanged.
+// One unified step: each walking lane visits ONE node and -- when at least `min_parked` lanes
+// are parked in a leaf, or nobody is walking -- each parked lane tests ONE triangle of its
+// leaf.  Both kinds of loads are issued together at the top.  Per-lane order of visits and
+// tests is unchanged; a lane resumes walking as soon as ITS leaf is done.
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ void walk_step(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                          uint32_t *stack, RayCounters &rc, unsigned long long walkers,
+                                          unsigned long long parked, int min_parked SHRAY_DIAG_PARAM)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.packed_tris);
+    const bool test_now = parked && (__popcll(parked) >= min_parked || !walkers);
+    const bool w = state == LT_WALK;
+    const bool p = test_now && state == LT_LEAF;
+    SHRAY_DIAG_COUNT(0);
+    if (test_now)
+        SHRAY_DIAG_COUNT(1);
+
+    float4 lo = make_float4(0, 0, 0, 0), hi = lo, q0 = lo, q1 = lo, q2 = lo;
+    const uint32_t which = t.leaf_first + t.leaf_j;
+    if (w) {
+        lo = nodes[2u * t.node];
+        hi = nodes[2u * t.node + 1u];
+    }
+    if (p) {
+        load_packed_triangle(tris + 3u * which, q0, q1, q2);
+    }
+    if (w)
+        state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+    if (p) {
+        lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
+        t.leaf_j++;
+        if (t.leaf_j == t.leaf_count)
+            state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+    }
+}
+
+// Unified loop: walk_step until every lane's traversal has ended.
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void walk_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
                                            uint32_t *stack, RayCounters &rc, int min_parked SHRAY_DIAG_PARAM)
 {
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.packed_tris);
     for (;;) {
         const unsigned long long walkers = wave_ballot(state == LT_WALK);
         const unsigned long long parked = wave_ballot(state == LT_LEAF);
         if (!(walkers | parked))
             return;
-        const bool test_now = parked && (__popcll(parked) >= min_parked || !walkers);
-        const bool w = state == LT_WALK;
-        const bool p = test_now && state == LT_LEAF;
-        SHRAY_DIAG_COUNT(0);
-        if (test_now)
-            SHRAY_DIAG_COUNT(1);
-
-        float4 lo = make_float4(0, 0, 0, 0), hi = lo, q0 = lo, q1 = lo, q2 = lo;
-        const uint32_t which = t.leaf_first + t.leaf_j;
-        if (w) {
-            lo = nodes[2u * t.node];
-            hi = nodes[2u * t.node + 1u];
-        }
-        if (p) {
-            q0 = tris[3u * which];
-            q1 = tris[3u * which + 1u];
-            q2 = tris[3u * which + 2u];
-        }
-        if (w)
-            state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
-        if (p) {
-            lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
-            t.leaf_j++;
-            if (t.leaf_j == t.leaf_count)
-                state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
-        }
+        walk_step<COUNT, BLOCK>(sc, fr, t, state, stack, rc, walkers, parked, min_parked SHRAY_DIAG_ARG_FWD);
     }
 }
 

@@ -54,6 +54,14 @@ int main(int argc, char **argv)
         float r1 = fmaf(-b, q1, a);
         float fast = fmaf(r1, y, q1);
         float exact = a / b;
+        /* four-operation form with a split reciprocal */
+        float yl = fmaf(-b, y, 1.0f) * y;
+        float p1 = fmaf(a, yl, a * y);
+        float fast4 = fmaf(fmaf(-b, p1, a), y, p1);
+        if (memcmp(&fast4, &exact, 4) != 0 && !(fast4 == 0.0f && exact == 0.0f)) {
+            if (bad < 5) fprintf(stderr, "mismatch4 a=%a b=%a fast4=%a exact=%a\n", a, b, fast4, exact);
+            bad++;
+        }
         if (memcmp(&fast, &exact, 4) != 0 && !(fast == 0.0f && exact == 0.0f)) {
             if (bad < 5) fprintf(stderr, "mismatch a=%a b=%a fast=%a exact=%a\n", a, b, fast, exact);
             bad++;

@@ -109,6 +109,8 @@ struct shray_scene {
     DeviceBuffer env;
     DeviceBuffer counters;
     DeviceBuffer work_counter;
+    DeviceBuffer patch_order;        // permutation of patch indices for the stack kernel (optional)
+    uint32_t patch_order_count = 0;
 
     SceneView view{};
 };
@@ -348,8 +350,10 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     return SHRAY_OK;
 }
 
-int launch(shray_scene *s, const FrameView &fr, float4 *d_out, DeviceCounters *d_counters, hipStream_t stream)
+int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters *d_counters, hipStream_t stream)
 {
+    FrameView fr = fr_in;
+    fr.patch_order = (s->patch_order.p && s->patch_order_count == fr.total_patches) ? (const uint32_t *)s->patch_order.p : nullptr;
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
@@ -677,6 +681,22 @@ int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, i
     }
     shray::g_diag_plain_kernel = false;
     HIP_TRY(hipMemcpy(stamps, (char *)dbg.p + sizeof(DeviceCounters) * kCounterShards, nstamps * 8, hipMemcpyDeviceToHost));
+    return SHRAY_OK;
+}
+#endif
+
+#ifdef SHRAY_EXPERIMENTS
+// experiment hook: install a workgroup -> patch permutation for the stack kernel
+int shray_debug_set_patch_order(shray_scene *scene, const uint32_t *order, uint32_t count)
+{
+    if (!scene)
+        return SHRAY_ERR_INVALID_ARGUMENT;
+    if (!order || count == 0) {
+        scene->patch_order_count = 0;
+        return SHRAY_OK;
+    }
+    HIP_TRY(scene->patch_order.upload(order, (size_t)count * 4));
+    scene->patch_order_count = count;
     return SHRAY_OK;
 }
 #endif

@@ -64,6 +64,7 @@ struct FrameView {
     int32_t patches_x;        // 16x16 patches per row (of the frame, or of one tile)
     int32_t patches_per_unit; // patches per frame / per tile
     uint32_t total_patches;   // grid size in patches
+    const uint32_t *patch_order; // optional: workgroup b renders patch patch_order[b] (a permutation); nullptr = identity
 };
 
 struct DeviceCounters {

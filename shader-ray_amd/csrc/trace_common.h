@@ -226,7 +226,7 @@ template <class Traversal, bool COUNT>
 __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                              DeviceCounters *counters, Traversal &trav)
 {
-    const unsigned int patch = blockIdx.x;
+    const unsigned int patch = fr.patch_order ? fr.patch_order[blockIdx.x] : blockIdx.x;
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #ifdef SHRAY_DIAGNOSTICS
     // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a

@@ -36,19 +36,21 @@ def log(*a):
 
 def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
     """The CPU oracle (oracle/, a port of the shader: the reference has no CPU tracer) on the
-    same frame, all host cores; repeated until ~budget_s of wall time."""
+    same frame, all host cores; repeated for ~budget_s of wall time."""
     import oracle
     threads = os.cpu_count() or 1
+    oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)   # warm-up (page faults, thread pool)
+    reps = 0
     t0 = time.perf_counter()
-    oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)
-    first = time.perf_counter() - t0
-    reps = max(1, min(500, int(budget_s / max(first, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    while True:
         oracle.render(desc, env, params, WIDTH, HEIGHT, SPP, threads=threads)
-    dt = (time.perf_counter() - t0) / reps
+        reps += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s or reps >= 2000:
+            break
+    dt = elapsed / reps
     return {"value": round(WIDTH * HEIGHT * SPP / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"the full {WIDTH}x{HEIGHT} frame of the same workload, {reps} repetitions ({dt:.2f} s each), "
+            "sample": f"the full {WIDTH}x{HEIGHT} frame of the same workload, {reps} repetitions in {elapsed:.1f} s, "
                       f"CPU oracle with {threads} threads"}
 
 
@@ -102,10 +104,11 @@ def main():
         scene.render_into(params, WIDTH, HEIGHT, SPP, out.data_ptr(), stream, tile_set)
 
     frame_out = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
+    split = multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device) if distributed else None
 
     def step():
         if distributed:
-            return multigpu.render_frame_distributed(render_tiles, WIDTH, HEIGHT, tile, tile, device=device)
+            return split.render(render_tiles)
         scene.render_into(params, WIDTH, HEIGHT, SPP, frame_out.data_ptr(), stream, None)
         return frame_out
 

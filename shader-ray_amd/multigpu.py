@@ -60,30 +60,48 @@ def max_tiles_per_rank(width: int, height: int, tile_w: int, tile_h: int, world:
     return (tiles_x * tiles_y + world - 1) // world
 
 
+class DistributedFrame:
+    """One frame split across the ranks of a torch.distributed group, reusable across frames.
+
+    All buffers are allocated once: this rank's packed tile buffer and, on rank 0, one
+    [world, max_tiles, tile_h, tile_w, 4] receive buffer whose rows are the gather targets, so a
+    frame is: render -> gather -> one permute/crop kernel.  Nothing synchronises with the host."""
+
+    def __init__(self, width: int, height: int, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE, group=None,
+                 device=None):
+        import torch
+        import torch.distributed as dist
+        self.width, self.height, self.tile_w, self.tile_h = width, height, tile_w, tile_h
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, self.world)
+        n = self.per_rank * tile_h * tile_w * 4
+        self.mine = torch.zeros(n, dtype=torch.float32, device=device)
+        self.tiles = N.TileSet(tile_w, tile_h, self.world, self.rank)
+        self.received = None
+        self.sink = None
+        if self.rank == 0:
+            self.received = torch.zeros(self.world, n, dtype=torch.float32, device=device)
+            self.sink = [self.received[r] for r in range(self.world)]
+
+    def render(self, render_tiles):
+        """`render_tiles(tile_set, out_tensor)` fills this rank's packed tiles (on a GPU box that
+        is Scene.render_into; the CPU rehearsal passes an oracle-backed stand-in).  Returns the
+        assembled [height, width, 4] frame on rank 0, None elsewhere."""
+        import torch.distributed as dist
+        render_tiles(self.tiles, self.mine)
+        if self.world == 1:
+            gathered = self.mine.view(1, self.per_rank, self.tile_h, self.tile_w, 4)
+            return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
+        dist.gather(self.mine, self.sink, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        gathered = self.received.view(self.world, self.per_rank, self.tile_h, self.tile_w, 4)
+        return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
+
+
 def render_frame_distributed(render_tiles, width: int, height: int, tile_w: int = DEFAULT_TILE,
                              tile_h: int = DEFAULT_TILE, group=None, device=None):
-    """One frame across the ranks of `group` (torch.distributed).
-
-    `render_tiles(tile_set, out_tensor)` must fill `out_tensor` (float32, flat, length
-    max_tiles*tile_h*tile_w*4, on `device`) with this rank's packed tiles -- on a GPU box
-    that is Scene.render_into; the CPU (gloo) rehearsal passes an oracle-backed stand-in.
-    Returns the assembled frame tensor on rank 0, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, world)
-    mine = torch.zeros(per_rank * tile_h * tile_w * 4, dtype=torch.float32, device=device)
-    render_tiles(N.TileSet(tile_w, tile_h, world, rank), mine)
-    if world == 1:
-        gathered = mine.view(1, per_rank, tile_h, tile_w, 4)
-        return assemble_tiles_torch(gathered, width, height, tile_w, tile_h)
-    sink = None
-    if rank == 0:
-        sink = [torch.empty_like(mine) for _ in range(world)]
-    dist.gather(mine, sink, dst=0, group=group)
-    if rank != 0:
-        return None
-    gathered = torch.stack(sink).view(world, per_rank, tile_h, tile_w, 4)
-    return assemble_tiles_torch(gathered, width, height, tile_w, tile_h)
+    """One-shot convenience wrapper around DistributedFrame."""
+    return DistributedFrame(width, height, tile_w, tile_h, group, device).render(render_tiles)

@@ -68,11 +68,12 @@ class DistributedFrame:
     frame is: render -> gather -> one permute/crop kernel.  Nothing synchronises with the host."""
 
     def __init__(self, width: int, height: int, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE, group=None,
-                 device=None):
+                 device=None, always_gather: bool = False):
         import torch
         import torch.distributed as dist
         self.width, self.height, self.tile_w, self.tile_h = width, height, tile_w, tile_h
         self.group = group
+        self.always_gather = always_gather   # run the collective even with one rank (rehearsal)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, self.world)
@@ -91,7 +92,7 @@ class DistributedFrame:
         assembled [height, width, 4] frame on rank 0, None elsewhere."""
         import torch.distributed as dist
         render_tiles(self.tiles, self.mine)
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             gathered = self.mine.view(1, self.per_rank, self.tile_h, self.tile_w, 4)
             return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
         dist.gather(self.mine, self.sink, dst=0, group=self.group)

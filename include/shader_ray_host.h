@@ -59,6 +59,12 @@ int shray_host_default_view(const shray_host_world *world, shray_host_view *view
 int shray_host_frame_params(shray_host_world *world, const shray_host_view *view, int width, int height,
                             shray_frame_params *params);
 
+/* load_background() (host/background.h): the reference's background argument (ray.cpp:1002-1075):
+ * "r, g, b", "grid", "rrggbb" or a Radiance .hdr file.  *pixels (3 floats per pixel, row 0 =
+ * bottom row) is malloc'ed; release it with shray_host_free_background. */
+int shray_host_load_background(const char *spec, int *width, int *height, float **pixels);
+void shray_host_free_background(float *pixels);
+
 /* Quiet (1) drops the loaders' progress chatter on stderr; errors still print. */
 void shray_host_set_quiet(int quiet);
 

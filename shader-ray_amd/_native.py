@@ -103,6 +103,8 @@ HOST_SYMBOLS = [
     ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
     ("shray_host_default_view", C.c_int, [C.c_void_p, C.POINTER(HostView)]),
     ("shray_host_frame_params", C.c_int, [C.c_void_p, C.POINTER(HostView), C.c_int, C.c_int, C.POINTER(FrameParams)]),
+    ("shray_host_load_background", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_float_p)]),
+    ("shray_host_free_background", None, [c_float_p]),
     ("shray_host_set_quiet", None, [C.c_int]),
 ]
 

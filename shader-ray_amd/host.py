@@ -94,3 +94,17 @@ class World:
         if self._lib.shray_host_frame_params(self._handle, C.byref(view), width, height, C.byref(params)) != 0:
             raise RuntimeError("frame parameter computation failed")
         return params
+
+
+def load_background(spec: str) -> np.ndarray:
+    """The reference's background argument (ray.cpp:1002-1075): "r, g, b", "grid", "rrggbb" or a
+    Radiance .hdr file -> float32 [height, width, 3], row 0 = bottom row of the picture."""
+    lib = N.load_host()
+    w, h = C.c_int(), C.c_int()
+    px = N.c_float_p()
+    if lib.shray_host_load_background(spec.encode(), C.byref(w), C.byref(h), C.byref(px)) != 0:
+        raise RuntimeError(f"cannot load background {spec!r} (see stderr)")
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.shray_host_free_background(px)

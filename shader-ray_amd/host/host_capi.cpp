@@ -1,8 +1,10 @@
 // host_capi.cpp -- extern "C" view of the host layer (include/shader_ray_host.h).
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
+#include "background.h"
 #include "bvh.h"
 #include "frame-params.h"
 #include "host-log.h"
@@ -126,5 +128,24 @@ int shray_host_frame_params(shray_host_world *world, const shray_host_view *view
     make_frame_params(world->w, s, width, height, params);
     return 0;
 }
+
+int shray_host_load_background(const char *spec, int *width, int *height, float **pixels)
+{
+    if (!spec || !width || !height || !pixels)
+        return -1;
+    float2Dimage image;
+    if (!load_background(spec, image))
+        return -1;
+    float *copy = (float *)malloc(image.pixels.size() * sizeof(float));
+    if (!copy)
+        return -1;
+    memcpy(copy, image.pixels.data(), image.pixels.size() * sizeof(float));
+    *width = image.width;
+    *height = image.height;
+    *pixels = copy;
+    return 0;
+}
+
+void shray_host_free_background(float *pixels) { free(pixels); }
 
 }   // extern "C"

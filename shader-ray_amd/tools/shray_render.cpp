@@ -4,8 +4,8 @@
 //
 //   shray_render model.{trisrc,obj} background [-o out.ppm] [-w W -h H] [-m material] [-d diffuse] [-s spp]
 //
-// background: "r, g, b" floats, "grid", or hex "rrggbb" (ray.cpp:1002-1035).  Image files
-// (the reference reads them through FreeImagePlus) are not supported.
+// background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
+// (host/background.cpp; the reference decodes image files through FreeImagePlus).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,37 +13,10 @@
 #include <string>
 #include <vector>
 
+#include "background.h"
 #include "frame-params.h"
 #include "shader_ray_hip.h"
 #include "world.h"
-
-static bool parse_background(const char *spec, std::vector<float> &rgb, int &w, int &h)
-{
-    float r, g, b;
-    unsigned int rx, gx, bx;
-    if (sscanf(spec, "%f, %f, %f", &r, &g, &b) == 3) {
-        rgb = {r, g, b};
-        w = h = 1;
-        return true;
-    }
-    if (strcmp(spec, "grid") == 0) {
-        w = 2048;
-        h = 1024;
-        rgb.assign((size_t)w * h * 3, 0.0f);
-        for (int j = 0; j < h; j++)
-            for (int i = 0; i < w; i++)
-                if ((i % 8) < 1 || (j % 8) < 1)
-                    for (int c = 0; c < 3; c++)
-                        rgb[3 * ((size_t)j * w + i) + c] = 1.0f;
-        return true;
-    }
-    if (sscanf(spec, "%2x%2x%2x", &rx, &gx, &bx) == 3) {
-        rgb = {rx / 255.0f, gx / 255.0f, bx / 255.0f};
-        w = h = 1;
-        return true;
-    }
-    return false;
-}
 
 int main(int argc, char **argv)
 {
@@ -68,12 +41,11 @@ int main(int argc, char **argv)
         fprintf(stderr, "Cannot set up world.\n");
         return EXIT_FAILURE;
     }
-    std::vector<float> env;
-    int env_w = 0, env_h = 0;
-    if (!parse_background(argv[2], env, env_w, env_h)) {
-        fprintf(stderr, "Unsupported background \"%s\" (image files need FreeImagePlus upstream; not available here)\n", argv[2]);
+    float2Dimage background;
+    if (!load_background(argv[2], background))
         return EXIT_FAILURE;
-    }
+    const std::vector<float> &env = background.pixels;
+    const int env_w = background.width, env_h = background.height;
 
     scene_shader_data data;
     get_shader_data(world, data, 2048);

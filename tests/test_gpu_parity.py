@@ -249,3 +249,27 @@ def test_error_paths(pkg, gpu, bunny, env_sky):
     with pytest.raises(N.ShrayError) as e:
         pkg.Scene(hand.desc, env_sky, device=0)
     assert e.value.code == -6
+
+
+def test_command_line_harness_writes_the_same_frame(pkg, gpu, tmp_path):
+    """tools/shray_render (the headless `./ray model background`, ray.cpp:954-1092 + the 's' key's
+    color.ppm, :730-787) produces the frame the library renders, quantised to 8 bits, top row first."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "shader-ray_amd", "tools", "shray_render")
+    exe = os.path.abspath(exe)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(exe)), "tools"], check=True, stdout=subprocess.DEVNULL)
+    model = os.path.join(GOLDEN, "lobed_528.trisrc")
+    out = str(tmp_path / "color.ppm")
+    subprocess.run([exe, model, "0.2, 0.4, 0.8", "-o", out, "-w", "96", "-h", "64", "-m", "6"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    blob = open(out, "rb").read()
+    header, rest = blob.split(b"\n", 1)
+    assert header == b"P6 96 64 255" and len(rest) == 96 * 64 * 3
+    got = np.frombuffer(rest, np.uint8).reshape(64, 96, 3)
+    world = pkg.World(model)
+    scene = pkg.Scene(world.flatten(), pkg.load_background("0.2, 0.4, 0.8"), device=0)
+    frame = scene.render(world.frame_params(96, 64, material=6), 96, 64, 1)
+    want = (np.clip(frame[::-1, :, :3], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(got, want)
+    scene.close()

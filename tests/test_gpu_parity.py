@@ -273,3 +273,107 @@ def test_command_line_harness_writes_the_same_frame(pkg, gpu, tmp_path):
     want = (np.clip(frame[::-1, :, :3], 0, 1) * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(got, want)
     scene.close()
+
+
+def test_axis_aligned_rays_take_the_true_division_path(pkg, gpu, oracle_mod):
+    """Odd frame sizes put pixel centres exactly on the view axis: D.x = 0 and/or D.y = 0, so the
+    slab test divides by zero (+-inf, or NaN where the origin lies on a slab plane).  Those lanes
+    must leave the hoisted-reciprocal path (csrc/exact_div.h) and still match the oracle bit for bit."""
+    import test_oracle_kat as kat
+    env = pkg.scenes.environment_hdr_sky(64)
+    # mirror quad whose box planes pass through x = 0 and y = 0: (lo - P) / D = 0 / 0 on the axis
+    quad = [[[0, 0, 0], [4, 0, 0], [4, 4, 0]], [[0, 0, 0], [4, 4, 0], [0, 4, 0]]]
+    for hand, W, H in ((single_leaf_scene(kat.mirror_quad()), 33, 17), (single_leaf_scene(quad), 17, 33)):
+        params = default_params(pkg, W, H, zoom=3.0, material=6)
+        scene = pkg.Scene(hand.desc, env, device=0)
+        check_against_oracle(oracle_mod, scene, hand.desc, env, params, W, H, 1, f"axis-aligned rays {W}x{H}")
+        scene.close()
+    # and on a real tree: bunny at 65 x 65 (centre column and row have a zero direction component)
+    world = pkg.World(helpers.small_trisrc())
+    desc = world.flatten()
+    scene = pkg.Scene(desc, env, device=0)
+    view = world.default_view()
+    view.object_position[:] = [-world.info.scene_center[0], -world.info.scene_center[1], -world.info.scene_center[2]]
+    params = world.frame_params(65, 65, view, material=0)
+    check_against_oracle(oracle_mod, scene, desc, env, params, 65, 65, 1, "axis-aligned rays through a BVH")
+    scene.close()
+
+
+@pytest.mark.parametrize("scale", [1e-24, 2e18])
+def test_coordinates_outside_the_fast_division_range(pkg, gpu, oracle_mod, tmp_path, scale):
+    """Scenes scaled far down / beyond 2^60: for the large one scene creation must turn the
+    hoisted-reciprocal slab test off (box coordinates outside [2^-70, 2^60): every lane divides);
+    results stay bit-identical either way.  (Neither object is actually hit: at 1e-24 every
+    determinant is below the shader's absolute 1e-7 epsilon, raytracer.es.fs:312-315, at 2e18
+    the triangle test's products overflow -- on both sides alike.)"""
+    pos, tri = pkg.scenes.lobed_sphere_mesh(16, 32, bumpiness=0.2, ears=False, scale=scale)
+    path = str(tmp_path / "scaled.obj")
+    pkg.scenes.write_obj(path, pos, tri)
+    world = pkg.World(path)
+    assert np.isfinite(world.info.scene_extent)
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(64)
+    scene = pkg.Scene(desc, env, device=0)
+    params = world.frame_params(64, 48, material=0)
+    check_against_oracle(oracle_mod, scene, desc, env, params, 64, 48, 1, f"scene scaled by {scale}")
+    scene.close()
+
+
+def test_box_plane_at_a_denormal_scale_coordinate(pkg, gpu, oracle_mod):
+    """A hand-built leaf whose box has a plane at 1e-30 with the camera at the origin: the slab
+    numerator is 1e-30, outside the ranges for which csrc/exact_div.h is proven, so the scene must
+    fall back to true division; the quad at z = -2 is hit and frames match bit for bit."""
+    from helpers import HandScene, END
+    quad = np.array([[[-3, -3, -2], [3, -3, -2], [3, 3, -2]], [[-3, -3, -2], [3, 3, -2], [-3, 3, -2]]], np.float32)
+    normals = np.tile(np.array([0, 0, 1], np.float32), (6, 1))
+    hm = np.full((8, 1, 2), END, dtype=np.float32)
+    hand = HandScene(quad.reshape(-1, 3), normals, [[-3.00001, -3.00001, -2.00001]], [[3.00001, 3.00001, 1e-30]], hm, [[0, 2]], 0)
+    env = pkg.scenes.environment_hdr_sky(64)
+    params = default_params(pkg, 48, 32, zoom=0.0, material=6)
+    scene = pkg.Scene(hand.desc, env, device=0)
+    want = check_against_oracle(oracle_mod, scene, hand.desc, env, params, 48, 32, 1, "box plane at 1e-30")
+    empty, _ = oracle_mod.render(kat_far_scene().desc, env, params, 48, 32, 1)
+    assert not np.array_equal(want, empty)      # the quad is visible
+    scene.close()
+
+
+def kat_far_scene():
+    import test_oracle_kat as kat
+    return kat.far_away_triangle()
+
+
+def test_depth_capped_tree_with_large_leaves(pkg, gpu, oracle_mod, tmp_path):
+    """BVH_MAX_DEPTH (bvh.cpp:60-79) forces leaves far above 10 triangles; the shader only ever
+    tests the first 10 of a leaf (raytracer.es.fs:412-417).  Built in a child process because
+    the build parameters are read once per process."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+from __graft_entry__ import load_package
+import helpers, oracle
+pkg = load_package()
+world = pkg.World(helpers.small_trisrc())
+assert world.info.max_level <= 4, world.info.max_level
+a = world.arrays()
+counts = a["group_objects"].reshape(-1, 2)[:, 1]
+assert counts.max() > 10
+desc = world.flatten()
+env = pkg.scenes.environment_hdr_sky(64)
+params = world.frame_params(96, 72, material=6)
+want, cpu = oracle.render(desc, env, params, 96, 72, 1)
+scene = pkg.Scene(desc, env, device=0)
+for kernel in (0, 1, 2):
+    scene.set_kernel(kernel)
+    got, gpu = scene.render_counters(params, 96, 72, 1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), kernel
+    assert gpu == cpu, (kernel, gpu, cpu)
+params.max_leaf_tests = 1000   # lifting the cap changes the image: the cap was active
+uncapped, _ = oracle.render(desc, env, params, 96, 72, 1)
+assert not np.array_equal(uncapped, want)
+print("ok")
+''' % (os.path.dirname(os.path.dirname(GOLDEN)), os.path.dirname(GOLDEN))
+    env = dict(os.environ, BVH_MAX_DEPTH="4")
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -50,6 +50,16 @@
 //     centre instead of being interpolated from the quad corners; the two
 //     agree up to float rounding because all four corner rays have one length.
 //     Row 0 of the output is the BOTTOM row (v = 0, vs:43-44).
+//   * `which` (fs:27, ray.cpp:46): 0 = normal.  2 and 3 are the shader's differential debug
+//     views (fs:147-149, :642-650), 5 its 5x5 supersampled "reference image" (fs:654-673);
+//     all three are restated here.  For 2 the rays carry the differentials of fs:58-63 through
+//     ray_transfer / ray_reflect exactly as written, including the vec3 - scalar of fs:92-93.
+//     pow(x, 1.5) (fs:623) is evaluated as x * sqrt(x).  For 5 the shader offsets the
+//     INTERPOLATED varying world_ray_direction (fs:663), which is the corner rays' common
+//     1/length times (ipw(u-.5), ipw(v-.5)aspect, -1): that is what is used here; its first,
+//     discarded trace (fs:652 overwritten at :656) is not executed.  1 (textureGrad with
+//     mip-maps and 4x anisotropy, fs:146) is not implemented and is rejected; any other value
+//     renders like 0, as in the shader.
 //   * spp > 1 (not in the reference except which==5, fs:654-673): sample s of
 //     n uses sub-pixel offset ((s+.5)/n, bitreverse32(s)*2^-32 + .5/n);
 //     linear radiance is summed in sample order, divided by n, then tone
@@ -181,9 +191,11 @@ struct Ctx {
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
 uint32_t *g_visit_map = nullptr;
 
-struct ray {   // fs:58-63 (differentials only matter for which in {1,2,3}; not carried here)
+struct ray {   // fs:58-63
     vec3 P, D;
+    vec3 dPdx, dDdx, dPdy, dDdy;
 };
+inline ray make_ray(vec3 P, vec3 D) { return ray{P, D, V(0, 0, 0), V(0, 0, 0), V(0, 0, 0), V(0, 0, 0)}; }
 
 struct surface_hit {   // fs:108-113
     float t, which;
@@ -336,7 +348,36 @@ inline surface_hit surface_hit_init() { return surface_hit{infinitely_far, -1.0f
 // fs:98-106 (P and D only)
 inline ray ray_transform(const ray &r, const float matrix[16], const float normal_matrix[16])
 {
-    return ray{transform(matrix, r.P, 1.0f), transform(normal_matrix, r.D, 0.0f)};
+    return make_ray(transform(matrix, r.P, 1.0f), transform(normal_matrix, r.D, 0.0f));
+}
+
+// fs:65-81
+inline ray ray_transfer(const ray &in, float t, vec3 normal)
+{
+    ray out;
+    out.P = in.P + in.D * t;
+    out.D = in.D;
+    const float dtdx = -dot(in.dPdx + t * in.dDdx, normal) / dot(in.D, normal);
+    out.dPdx = in.dPdx + t * in.dDdx + dtdx * in.D;
+    out.dDdx = in.dDdx;
+    const float dtdy = -dot(in.dPdy + t * in.dDdy, normal) / dot(in.D, normal);
+    out.dPdy = in.dPdy + t * in.dDdy + dtdy * in.D;
+    out.dDdy = in.dDdy;
+    return out;
+}
+
+// fs:83-96; the direction differentials lose a SCALAR per component, as written ("do this right")
+inline ray ray_reflect(const ray &in, vec3 normal)
+{
+    ray out;
+    out.D = reflect(in.D, normal);
+    out.P = in.P + normal * .0001f;
+    out.dPdx = in.dPdx;
+    out.dPdy = in.dPdy;
+    const float sx = 2 * dot(in.dDdx, normal), sy = 2 * dot(in.dDdy, normal);
+    out.dDdx = V(in.dDdx.x - sx, in.dDdx.y - sx, in.dDdx.z - sx);
+    out.dDdy = V(in.dDdy.x - sy, in.dDdy.y - sy, in.dDdy.z - sy);
+    return out;
 }
 
 // fs:288-295
@@ -358,7 +399,7 @@ vec3 approximate_diffuse(Ctx &cx, vec3 point, vec3 normal)
     vec3 diffuse = V(0.0f, 0.0f, 0.0f);                      // ambient
     if (p.cast_shadows) {
         surface_hit shadow_hit = surface_hit_init();
-        const ray world_shadowray{point, light_dir};
+        const ray world_shadowray = make_ray(point, light_dir);
         const ray object_shadowray = ray_transform(world_shadowray, p.object_matrix, p.object_normal_matrix);
         group_intersect(cx, cx.scene->tree_root, object_shadowray, make_range(0.0f, 100000000.0f), shadow_hit);
         if (shadow_hit.t >= infinitely_far)
@@ -402,10 +443,13 @@ int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3
     if (dot(world_normal, worldray.D) > 0.0f)
         world_normal = world_normal * -1.0f;
 
-    // ray_transfer fs:65-81, ray_reflect fs:83-96 (P, D only)
-    ray transferred{worldray.P + worldray.D * shading.t, worldray.D};
-    reflected.D = reflect(transferred.D, world_normal);
-    reflected.P = transferred.P + world_normal * .0001f;
+    // ray_transfer fs:65-81, ray_reflect fs:83-96.  P and D do not depend on the differentials;
+    // the differentials are only carried when a view needs them (which == 2)
+    if (p.which == 2) {
+        reflected = ray_reflect(ray_transfer(worldray, shading.t, world_normal), world_normal);
+    } else {
+        reflected = make_ray(worldray.P + worldray.D * shading.t + world_normal * .0001f, reflect(worldray.D, world_normal));
+    }
 
     object_specular = f_schlick_vr(V(p.specular_color[0], p.specular_color[1], p.specular_color[2]), worldray.D, reflected.D);
     object_diffuse = V(p.diffuse_color[0], p.diffuse_color[1], p.diffuse_color[2]) * object_color;
@@ -418,6 +462,12 @@ vec3 sample_environment(Ctx &cx, const ray &r)
 {
     cx.c.env_lookups++;
     const Scene &sc = *cx.scene;
+    if (cx.p->which == 2) {   // fs:135-149: draw the dY differential of the lookup coordinates
+        const float two_pi_rxz = 2.0f * pi * (r.D.x * r.D.x + r.D.z * r.D.z);
+        const float dudy = (r.D.x * r.dDdy.z - r.D.z * r.dDdy.x) / two_pi_rxz;
+        const float dvdy = r.dDdy.y / (pi * sqrtf(1.0f - r.D.y * r.D.y));
+        return V(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+    }
     const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
     const float s = 1.0f + sr_atan2(-r.D.z, r.D.x) / tau;
     const float t = 1.0f - sr_acos(dy) / pi;
@@ -483,17 +533,85 @@ inline uint32_t bitreverse32(uint32_t v)
 }
 
 // vs:39-60 evaluated at image-plane position (u, v), then fs:617-619
+// fs:621-625: direction differentials of a ray through the image plane
+inline void set_differentials(const shray_frame_params &p, ray &r)
+{
+    const vec3 right = V(p.right[0], p.right[1], p.right[2]), up = V(p.up[0], p.up[1], p.up[2]);
+    const vec3 d = r.D;
+    const float dd = dot(d, d);
+    const float dd15 = dd * sqrtf(dd);   // pow(dot(d, d), 1.5)
+    r.dPdx = V(0, 0, 0);
+    r.dDdx = (dd * right - dot(d, right) * d) / dd15;
+    r.dPdy = V(0, 0, 0);
+    r.dDdy = (dd * up - dot(d, up) * d) / dd15;
+}
+
 ray primary_ray(const shray_frame_params &p, float u, float v)
 {
     const vec3 eye_d = normalize(V(p.image_plane_width * (u - 0.5f), p.image_plane_width * (v - 0.5f) * p.aspect, -1.0f));
-    ray world = ray_transform(ray{V(0, 0, 0), eye_d}, p.camera_matrix, p.camera_normal_matrix);
+    ray world = ray_transform(make_ray(V(0, 0, 0), eye_d), p.camera_matrix, p.camera_normal_matrix);
     world.D = normalize(world.D);
+    if (p.which == 2 || p.which == 3)
+        set_differentials(p, world);
     return world;
+}
+
+// The varyings of vs:58-59 as the rasteriser interpolates them at (u, v): every corner ray is
+// divided by the same length, so the interpolated direction is the unnormalised image-plane
+// vector over that length (used by the which == 5 view, fs:663).
+inline void interpolated_varyings(const shray_frame_params &p, float u, float v, vec3 &origin, vec3 &direction)
+{
+    const float hx = p.image_plane_width * (1.0f - 0.5f), hy = p.image_plane_width * (1.0f - 0.5f) * p.aspect;
+    const float corner_length = sqrtf(dot(V(hx, hy, -1.0f), V(hx, hy, -1.0f)));
+    const vec3 eye = V(p.image_plane_width * (u - 0.5f), p.image_plane_width * (v - 0.5f) * p.aspect, -1.0f) / corner_length;
+    origin = transform(p.camera_matrix, V(0, 0, 0), 1.0f);
+    direction = transform(p.camera_normal_matrix, eye, 0.0f);
+}
+
+// fs:121-125
+inline void environment_map_coords(vec3 d, float &s, float &t)
+{
+    s = 1.0f + sr_atan2(-d.z, d.x) / tau;
+    t = 1.0f - sr_acos(gl_min(gl_max(d.y, -1.0f), 1.0f)) / pi;
 }
 
 void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float out[4])
 {
     const shray_frame_params &p = *cx.p;
+    if (p.which == 3) {   // fs:642-650: the pixel's own differentials, no trace, no tone map
+        const ray r = primary_ray(p, ((float)px + 0.5f) / (float)width, ((float)py + 0.5f) / (float)height);
+        float sb, tb, sa, ta;
+        environment_map_coords(r.D - r.dDdy / 2.0f, sb, tb);
+        environment_map_coords(r.D + r.dDdy / 2.0f, sa, ta);
+        out[0] = fabsf(sa - sb) * 1.0f * 100;
+        out[1] = fabsf(ta - tb) * 1.0f * 100;
+        out[2] = 0.0f;
+        out[3] = 1.0f;
+        return;
+    }
+    if (p.which == 5) {   // fs:654-673: 5 x 5 supersampled reference image
+        const vec3 right = V(p.right[0], p.right[1], p.right[2]), up = V(p.up[0], p.up[1], p.up[2]);
+        vec3 origin, direction;
+        interpolated_varyings(p, ((float)px + 0.5f) / (float)width, ((float)py + 0.5f) / (float)height, origin, direction);
+        vec3 result = V(0, 0, 0);
+        const int blarg = 5;
+        for (int i = 0; i < blarg; i++) {
+            for (int j = 0; j < blarg; j++) {
+                const float u = ((float)i / float(blarg) - .5f);
+                const float v = ((float)j / float(blarg) - .5f);
+                const ray r = make_ray(origin, normalize(direction + u * .2f * right + v * .2f * up));
+                result = result + trace(cx, r);
+            }
+        }
+        result = result / (float)(blarg * blarg);
+        if (p.tonemap)
+            result = V(filmic(result.x), filmic(result.y), filmic(result.z));
+        out[0] = result.x;
+        out[1] = result.y;
+        out[2] = result.z;
+        out[3] = 1.0f;
+        return;
+    }
     vec3 sum = V(0, 0, 0);
     const uint64_t visits_before = cx.c.node_visits + (cx.c.triangle_tests << 32);
     for (int s = 0; s < spp; s++) {
@@ -535,8 +653,8 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
 {
     if (!desc || !env_rgb || !params || !rgba_out || width <= 0 || height <= 0 || spp <= 0 || env_w <= 0 || env_h <= 0)
         return -1;
-    if (params->which != 0)
-        return -1;
+    if (params->which == 1 || ((params->which == 3 || params->which == 5) && spp != 1))
+        return -1;   // textureGrad view not implemented; the 3 / 5 views are per-pixel, not per-sample
     row_begin = std::max(0, row_begin);
     row_end = std::min(height, row_end);
 

@@ -286,10 +286,12 @@ int validate_params(const shray_frame_params *p, int width, int height, int spp)
                     p->struct_size, sizeof(shray_frame_params));
     if (width <= 0 || height <= 0 || spp <= 0 || width > 65536 || height > 65536 || spp > (1 << 20))
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad frame geometry %dx%d, %d spp", width, height, spp);
-    if (p->which != 0)
+    if (p->which == 1)
         return fail(SHRAY_ERR_INVALID_ARGUMENT,
-                    "which = %d: only the normal rendering mode (0) is implemented; the reference's debug views "
-                    "(1, 2, 3, 5) are not", p->which);
+                    "which = 1 (environment lookup through textureGrad with mip-maps and 4x anisotropy, "
+                    "raytracer.es.fs:146) is not implemented; 0, 2, 3, 5 are");
+    if ((p->which == 3 || p->which == 5) && spp != 1)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "which = %d is a per-pixel view; spp must be 1", p->which);
     if (p->bounce_count < 0 || p->bounce_count > 64 || p->max_bvh_iterations < 1 || p->max_bvh_iterations > (1 << 24) ||
         p->max_leaf_tests < 0 || p->max_leaf_tests > (1 << 24))
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "shader constants out of range (bounce_count %d, max_bvh_iterations %d, "
@@ -317,6 +319,9 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     fr->cast_shadows = p->cast_shadows;
     fr->tonemap = p->tonemap;
     fr->normals_fp16 = p->normals_fp16;
+    fr->which = p->which;
+    memcpy(fr->right, p->right, 12);
+    memcpy(fr->up, p->up, 12);
     fr->width = width;
     fr->height = height;
     fr->spp = spp;
@@ -357,10 +362,11 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
-    if (s->kernel_id == 2 && s->packed_ok)
+    const bool view = fr.which == 2 || fr.which == 3 || fr.which == 5;
+    if (s->kernel_id == 2 && s->packed_ok && !view)
         e = launch_persistent(s->view, fr, d_out, d_counters, stream, s->stack_levels,
                               (unsigned int *)s->work_counter.p, s->resident_blocks);
-    else if (s->kernel_id == 0 && s->packed_ok)
+    else if (s->kernel_id != 1 && s->packed_ok)
         e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else
         e = launch_threaded(s->view, fr, d_out, d_counters, stream);

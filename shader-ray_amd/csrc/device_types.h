@@ -55,6 +55,8 @@ struct FrameView {
     float diffuse_color[3];
     int32_t bounce_count, max_bvh_iterations, max_leaf_tests;
     int32_t cast_shadows, tonemap, normals_fp16;
+    int32_t which;            // 0 normal; 2, 3, 5: the shader's debug / reference views
+    float right[3], up[3];    // one-pixel steps on the image plane (ray differentials)
 
     int32_t width, height, spp;
     // tiling: tile_stride == 0 means "whole frame, row-major output"

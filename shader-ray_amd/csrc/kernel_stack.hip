@@ -22,13 +22,13 @@ bool g_diag_plain_kernel = false;
 #define SHRAY_LDS_PAD 0
 #endif
 
-template <bool COUNT>
+template <bool COUNT, bool DIFF>
 __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
 {
     extern __shared__ uint32_t lds_stack[];
     StackTraversal<kBlock> trav;
     trav.stack = lds_stack + threadIdx.x;
-    trace_pixels<StackTraversal<kBlock>, COUNT>(sc, fr, out, counters, trav);
+    trace_pixels<StackTraversal<kBlock>, COUNT, DIFF>(sc, fr, out, counters, trav);
 }
 
 hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
@@ -38,14 +38,19 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
     const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + SHRAY_LDS_PAD;
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && g_diag_plain_kernel) {
-        hipLaunchKernelGGL(trace_stack_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+        hipLaunchKernelGGL((trace_stack_kernel<false, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
         return hipGetLastError();
     }
 #endif
-    if (counters)
-        hipLaunchKernelGGL(trace_stack_kernel<true>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+    const bool diff = fr.which == 2;   // only that view needs the ray differentials carried along
+    if (counters && diff)
+        hipLaunchKernelGGL((trace_stack_kernel<true, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+    else if (counters)
+        hipLaunchKernelGGL((trace_stack_kernel<true, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+    else if (diff)
+        hipLaunchKernelGGL((trace_stack_kernel<false, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
     else
-        hipLaunchKernelGGL(trace_stack_kernel<false>, grid, block, lds_bytes, stream, sc, fr, out, counters);
+        hipLaunchKernelGGL((trace_stack_kernel<false, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
     return hipGetLastError();
 }
 

@@ -150,12 +150,59 @@ __device__ __forceinline__ float filmic(float c)
     return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
 }
 
+// Ray differentials of fs:58-63, carried only by the which == 2 view.
+struct Differentials {
+    V3 dPdx, dDdx, dPdy, dDdy;
+};
+
+// fs:621-625; pow(dot(d, d), 1.5) is evaluated as x * sqrt(x) (as in the oracle)
+__device__ __forceinline__ void primary_differentials(const FrameView &fr, V3 d, Differentials &df)
+{
+    const V3 right = mk(fr.right[0], fr.right[1], fr.right[2]), up = mk(fr.up[0], fr.up[1], fr.up[2]);
+    const float dd = dot3(d, d);
+    const float dd15 = dd * sqrtf(dd);
+    df.dPdx = mk(0, 0, 0);
+    df.dDdx = (right * dd - d * dot3(d, right)) / dd15;
+    df.dPdy = mk(0, 0, 0);
+    df.dDdy = (up * dd - d * dot3(d, up)) / dd15;
+}
+
+// ray_transfer (fs:65-81) then ray_reflect (fs:83-96) applied to the differentials; the direction
+// differentials lose a SCALAR per component in the reflection, exactly as the shader is written
+__device__ __forceinline__ void bounce_differentials(Differentials &df, V3 D, float t, V3 n)
+{
+    const float dn = dot3(D, n);
+    const V3 ax = df.dPdx + df.dDdx * t, ay = df.dPdy + df.dDdy * t;
+    const float dtdx = -dot3(ax, n) / dn, dtdy = -dot3(ay, n) / dn;
+    df.dPdx = ax + D * dtdx;
+    df.dPdy = ay + D * dtdy;
+    const float sx = 2 * dot3(df.dDdx, n), sy = 2 * dot3(df.dDdy, n);
+    df.dDdx = mk(df.dDdx.x - sx, df.dDdx.y - sx, df.dDdx.z - sx);
+    df.dDdy = mk(df.dDdy.x - sy, df.dDdy.y - sy, df.dDdy.z - sy);
+}
+
+// sample_environment with which == 2 (fs:135-149): |d(s,t)/dy| * 100 instead of a texel
+__device__ __forceinline__ V3 environment_dy_view(V3 D, const Differentials &df)
+{
+    const float two_pi_rxz = 2.0f * kPi * (D.x * D.x + D.z * D.z);
+    const float dudy = (D.x * df.dDdy.z - D.z * df.dDdy.x) / two_pi_rxz;
+    const float dvdy = df.dDdy.y / (kPi * sqrtf(1.0f - D.y * D.y));
+    return mk(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+}
+
+// get_environment_map_coords, fs:121-125
+__device__ __forceinline__ void environment_coords(V3 d, float &s, float &t)
+{
+    s = 1.0f + atan_yx(-d.z, d.x) / (2 * kPi);
+    t = 1.0f - acos_clamped(sel_min(sel_max(d.y, -1.0f), 1.0f)) / kPi;
+}
+
 // trace(), fs:552-582, with intersect_and_shade (fs:484-522) and
 // approximate_diffuse (fs:447-472) inlined.  Traversal::closest() runs
 // group_intersect (fs:386-443) on an object-space ray.
-template <class Traversal, bool COUNT>
+template <class Traversal, bool COUNT, bool DIFF>
 __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr, Traversal &trav, V3 P, V3 D,
-                                       RayCounters &rc)
+                                       RayCounters &rc, Differentials df = Differentials())
 {
     V3 accumulated = mk(0, 0, 0);
     V3 modulation = mk(1, 1, 1);
@@ -182,6 +229,8 @@ __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr
         if (dot3(n, D) > 0.0f)
             n = n * -1.0f;
 
+        if (DIFF)
+            bounce_differentials(df, D, hit.t, n);
         const V3 at = P + D * hit.t;                      // ray_transfer, fs:69
         const V3 R = D - n * (2.0f * dot3(n, D));         // reflect(), fs:86
         const V3 P2 = at + n * .0001f;                    // surface fudge, fs:87
@@ -208,6 +257,8 @@ __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr
     }
     if (COUNT)
         rc.env_lookups++;
+    if (DIFF)
+        return accumulated + modulation * environment_dy_view(D, df);
     return accumulated + modulation * environment(sc, D);
 }
 
@@ -222,7 +273,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 
 // One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four
 // 8x8 wave tiles so that the 64 rays of a wave stay spatially coherent.
-template <class Traversal, bool COUNT>
+template <class Traversal, bool COUNT, bool DIFF = false>
 __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                              DeviceCounters *counters, Traversal &trav)
 {
@@ -259,7 +310,38 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
 
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
     V3 result = mk(0, 0, 0);
-    if (inside) {
+    if (inside && fr.which == 3) {
+        // fs:642-650: this pixel's own dY differential of the lookup coordinates; no trace, no tone map
+        const float u = ((float)px + 0.5f) / (float)fr.width, v = ((float)py + 0.5f) / (float)fr.height;
+        const V3 eye = unit(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f));
+        const V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
+        Differentials df;
+        primary_differentials(fr, D, df);
+        float sb, tb, sa, ta;
+        environment_coords(D - df.dDdy / 2.0f, sb, tb);
+        environment_coords(D + df.dDdy / 2.0f, sa, ta);
+        result = mk(fabsf(sa - sb) * 1.0f * 100, fabsf(ta - tb) * 1.0f * 100, 0.0f);
+    } else if (inside && fr.which == 5) {
+        // fs:654-673: 5 x 5 supersampled reference image around the interpolated varying direction
+        const float u = ((float)px + 0.5f) / (float)fr.width, v = ((float)py + 0.5f) / (float)fr.height;
+        const float hx = fr.image_plane_width * (1.0f - 0.5f), hy = fr.image_plane_width * (1.0f - 0.5f) * fr.aspect;
+        const float corner_length = sqrtf(dot3(mk(hx, hy, -1.0f), mk(hx, hy, -1.0f)));
+        const V3 eye = mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f) / corner_length;
+        const V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
+        const V3 dir = xform(fr.camera_normal_matrix, eye, 0.0f);
+        const V3 right = mk(fr.right[0], fr.right[1], fr.right[2]), up = mk(fr.up[0], fr.up[1], fr.up[2]);
+        V3 acc = mk(0, 0, 0);
+        for (int i = 0; i < 5; i++) {
+            for (int j = 0; j < 5; j++) {
+                const float du = ((float)i / 5.0f - .5f), dv = ((float)j / 5.0f - .5f);
+                const V3 D = unit(dir + right * (du * .2f) + up * (dv * .2f));
+                acc = acc + trace_ray<Traversal, COUNT, false>(sc, fr, trav, P, D, rc);
+            }
+        }
+        result = acc / 25.0f;
+        if (fr.tonemap)
+            result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
+    } else if (inside) {
         const float fw = (float)fr.width, fh = (float)fr.height, fn = (float)fr.spp;
         V3 sum = mk(0, 0, 0);
         for (int s = 0; s < fr.spp; s++) {
@@ -272,7 +354,10 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
             const V3 eye = unit(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f));
             const V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
             const V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
-            const V3 radiance = trace_ray<Traversal, COUNT>(sc, fr, trav, P, D, rc);
+            Differentials df;
+            if (DIFF)
+                primary_differentials(fr, D, df);
+            const V3 radiance = trace_ray<Traversal, COUNT, DIFF>(sc, fr, trav, P, D, rc, df);
             sum = (fr.spp == 1) ? radiance : sum + radiance;
         }
         result = (fr.spp == 1) ? sum : sum / fn;

@@ -377,3 +377,25 @@ print("ok")
     env = dict(os.environ, BVH_MAX_DEPTH="4")
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("which,material", [(2, 0), (2, 6), (3, 0), (5, 0), (5, 6), (4, 0)])
+def test_which_views(pkg, gpu, oracle_mod, bunny, env_sky, which, material):
+    """The shader's `which` views (raytracer.es.fs:27): 2 = differential of the environment lookup
+    carried through the bounces, 3 = the pixel's own differentials, 5 = 5x5 supersampled
+    reference image; other values render like 0.  Bit-identical to the oracle, counters equal."""
+    world, desc, scene = bunny
+    params = world.frame_params(112, 80, material=material)
+    params.which = which
+    got = check_against_oracle(oracle_mod, scene, desc, env_sky, params, 112, 80, 1, f"which {which} material {material}")
+    if which == 4:
+        params.which = 0
+        base, _ = oracle_mod.render(desc, env_sky, params, 112, 80, 1)
+        assert np.array_equal(got, base)
+    if which == 3:
+        assert np.all(got[..., 2] == 0) and np.all(got[..., 3] == 1)
+    with pytest.raises(pkg._native.ShrayError):
+        if which in (3, 5):
+            scene.render(params, 112, 80, 2)      # per-pixel views: spp must be 1
+        else:
+            raise pkg._native.ShrayError(-1, "n/a")

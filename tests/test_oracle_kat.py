@@ -296,3 +296,101 @@ def test_specified_transcendentals_are_accurate(oracle_mod):
     assert oracle_mod.atan2(0.0, -1.0) == float(np.float32(np.pi)) and oracle_mod.atan2(1.0, 0.0) == float(np.float32(np.pi / 2))
     for b in (0.0, 1.0, 0.5, 0.999, 1e-3, 0.37):
         assert oracle_mod.pow5(b) == pytest.approx(b ** 5, rel=4e-7, abs=1e-45)
+
+
+# ---- the shader's `which` views (raytracer.es.fs:27, :144-154, :642-673)
+
+def coords64(d):
+    d = np.asarray(d, np.float64)
+    return np.array([1.0 + np.arctan2(-d[2], d[0]) / (2 * np.pi), 1.0 - np.arccos(np.clip(d[1], -1, 1)) / np.pi])
+
+
+def differentials64(p, d):
+    right, up = np.array(p.right[:], np.float64), np.array(p.up[:], np.float64)
+    dd = d @ d
+    return (dd * right - (d @ right) * d) / dd ** 1.5, (dd * up - (d @ up) * d) / dd ** 1.5
+
+
+def test_view_3_draws_the_pixel_differentials(pkg, oracle_mod):
+    """which == 3 (fs:642-650): |coords(d + dDdy/2) - coords(d - dDdy/2)| * 100, alpha 1, no
+    trace and no tone map."""
+    W, H = 64, 36
+    p = default_params(pkg, W, H)
+    p.which = 3
+    img, c = oracle_mod.render(far_away_triangle().desc, pkg.scenes.environment_constant((1, 1, 1)), p, W, H)
+    assert c["traversals"] == 0 and c["env_lookups"] == 0
+    for (px, py) in ((0, 0), (63, 35), (20, 30), (40, 5)):
+        d = pixel_dir64(p, px, py, W, H)
+        _, ddy = differentials64(p, d)
+        want = np.abs(coords64(d + ddy / 2) - coords64(d - ddy / 2)) * 100
+        assert np.allclose(img[py, px, :2], want, rtol=2e-3, atol=1e-6), (px, py)
+        assert img[py, px, 2] == 0.0 and img[py, px, 3] == 1.0
+    # one pixel step in y moves the lookup by about that much: compare with neighbouring pixel centres
+    d0, d1 = pixel_dir64(p, 30, 10, W, H), pixel_dir64(p, 30, 11, W, H)
+    assert np.allclose(img[10, 30, :2], np.abs(coords64(d1) - coords64(d0)) * 100, rtol=0.05)
+
+
+def test_view_2_draws_the_environment_derivative(pkg, oracle_mod):
+    """which == 2 (fs:135-149): the analytic d(s, t)/dy of the lookup, times 100, goes through
+    trace() and the tone map in place of a texel; checked against central differences."""
+    W, H = 64, 36
+    p = default_params(pkg, W, H)
+    p.which = 2
+    p.tonemap = 0
+    img, c = oracle_mod.render(far_away_triangle().desc, pkg.scenes.environment_constant((1, 1, 1)), p, W, H)
+    assert c["env_lookups"] == W * H
+    for (px, py) in ((5, 5), (50, 30), (32, 18)):
+        d = pixel_dir64(p, px, py, W, H)
+        _, ddy = differentials64(p, d)
+        eps = 1e-3
+        fd = (coords64(d + eps * ddy) - coords64(d - eps * ddy)) / (2 * eps)
+        assert np.allclose(img[py, px, :2], np.abs(fd) * 100, rtol=2e-3, atol=1e-6), (px, py)
+    # after a mirror bounce the differentials are transferred and reflected as the shader writes it
+    scene = single_leaf_scene(mirror_quad())
+    p2 = default_params(pkg, 16, 16, zoom=3.0)
+    p2.which = 2
+    img2, c2 = oracle_mod.render(scene.desc, pkg.scenes.environment_constant((1, 1, 1)), p2, 16, 16)
+    assert c2["shaded_hits"] == 256 and np.isfinite(img2).all() and (img2[..., :2] > 0).any()
+
+
+def test_view_5_is_the_mean_of_25_rays(pkg, oracle_mod):
+    """which == 5 (fs:654-673): 5 x 5 rays around the interpolated varying direction, averaged
+    in linear radiance, then tone mapped once."""
+    W, H = 40, 24
+    env = pkg.scenes.environment_hdr_sky(64)
+    p = default_params(pkg, W, H)
+    p.which = 5
+    img, c = oracle_mod.render(far_away_triangle().desc, env, p, W, H)
+    assert c["env_lookups"] == 25 * W * H and c["samples"] == W * H
+    right, up = np.array(p.right[:], np.float64), np.array(p.up[:], np.float64)
+    hx, hy = p.image_plane_width * 0.5, p.image_plane_width * 0.5 * p.aspect
+    corner_len = np.sqrt(hx * hx + hy * hy + 1)
+    for (px, py) in ((0, 0), (39, 23), (17, 9)):
+        u, v = (px + 0.5) / W, (py + 0.5) / H
+        direction = np.array([p.image_plane_width * (u - 0.5), p.image_plane_width * (v - 0.5) * p.aspect, -1.0]) / corner_len
+        acc = np.zeros(3)
+        for i in range(5):
+            for j in range(5):
+                d = direction + (i / 5 - 0.5) * 0.2 * right + (j / 5 - 0.5) * 0.2 * up
+                acc += env_bilinear64(env, d / np.linalg.norm(d))
+        assert np.allclose(img[py, px, :3], filmic64(acc / 25), rtol=3e-5, atol=1e-6), (px, py)
+    # a constant environment makes it indistinguishable from the normal view
+    cenv = pkg.scenes.environment_constant((0.3, 0.6, 0.9))
+    a, _ = oracle_mod.render(far_away_triangle().desc, cenv, p, W, H)
+    p.which = 0
+    b, _ = oracle_mod.render(far_away_triangle().desc, cenv, p, W, H)
+    assert np.allclose(a, b, rtol=1e-6)
+
+
+def test_other_which_values_render_like_0_and_1_is_rejected(pkg, oracle_mod):
+    scene = single_leaf_scene(mirror_quad())
+    env = pkg.scenes.environment_hdr_sky(64)
+    p = default_params(pkg, 12, 12, zoom=3.0)
+    base, _ = oracle_mod.render(scene.desc, env, p, 12, 12)
+    for w in (4, 6, -1):   # fs:627-628 (empty branch), and the else-branch of fs:150-154
+        p.which = w
+        img, _ = oracle_mod.render(scene.desc, env, p, 12, 12)
+        assert np.array_equal(img, base)
+    p.which = 1
+    with pytest.raises(RuntimeError):
+        oracle_mod.render(scene.desc, env, p, 12, 12)

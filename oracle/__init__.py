@@ -34,7 +34,7 @@ def load():
         _lib.shray_oracle_filmic.argtypes = [C.c_float]
         _lib.shray_oracle_half.restype = C.c_float
         _lib.shray_oracle_half.argtypes = [C.c_float]
-        for name, nargs in (("shray_oracle_atan2", 2), ("shray_oracle_acos", 1), ("shray_oracle_pow5", 1)):
+        for name, nargs in (("shray_oracle_atan2", 2), ("shray_oracle_acos", 1), ("shray_oracle_pow5", 1), ("shray_oracle_log2", 1)):
             fn = getattr(_lib, name)
             fn.restype = C.c_float
             fn.argtypes = [C.c_float] * nargs
@@ -79,6 +79,19 @@ def acos(x: float) -> float:
 
 def pow5(x: float) -> float:
     return float(load().shray_oracle_pow5(x))
+
+
+def log2(x: float) -> float:
+    return float(load().shray_oracle_log2(x))
+
+
+def texture_grad(image: np.ndarray, s: float, t: float, dudx: float, dvdx: float, dudy: float, dvdy: float):
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    h, w, _ = image.shape
+    out = (C.c_float * 3)()
+    load().shray_oracle_texture_grad(image.ctypes.data_as(C.c_void_p), C.c_int(w), C.c_int(h), C.c_float(s), C.c_float(t),
+                                     C.c_float(dudx), C.c_float(dvdx), C.c_float(dudy), C.c_float(dvdy), out)
+    return np.array(out[:], dtype=np.float32)
 
 
 def schlick(cspec, v, r):

@@ -57,9 +57,19 @@
 //     pow(x, 1.5) (fs:623) is evaluated as x * sqrt(x).  For 5 the shader offsets the
 //     INTERPOLATED varying world_ray_direction (fs:663), which is the corner rays' common
 //     1/length times (ipw(u-.5), ipw(v-.5)aspect, -1): that is what is used here; its first,
-//     discarded trace (fs:652 overwritten at :656) is not executed.  1 (textureGrad with
-//     mip-maps and 4x anisotropy, fs:146) is not implemented and is rejected; any other value
-//     renders like 0, as in the shader.
+//     discarded trace (fs:652 overwritten at :656) is not executed.  Any value other than
+//     1, 2, 3, 5 renders like 0, as in the shader.
+//   * which == 1 (fs:144-146): textureGrad on a mip-mapped texture (LINEAR_MIPMAP_LINEAR, MAG
+//     LINEAR, 4x anisotropy, ray.cpp:503-509).  OpenGL leaves parts of this open; the rule fixed
+//     here (and in the kernel) is: mip level k+1 = 2x2 box filter of level k, ((a+b)+(c+d))*0.25,
+//     dimensions max(1, n/2), down to 1x1 (glGenerateMipmap's recommended filter);
+//     Px = |(du/dx * W, dv/dx * H)|, Py likewise (GL 3.1 section 3.8.9 scale factors);
+//     N = min(ceil(Pmax/Pmin), 4) probes, lambda = log2(Pmax / N), probes at
+//     P + (i/(N+1) - 1/2) * (major-axis derivative), i = 1..N, averaged
+//     (EXT_texture_filter_anisotropic's reference formulas); each probe is LINEAR at level 0 when
+//     lambda <= 0, else a blend of the two nearest levels by frac(lambda), clamped to the last
+//     level; log2 is the explicit fp32 sequence sr_log2 below; non-finite derivatives (rays
+//     straight up or down, fs:135-139 divide by zero there) select the 1x1 level.
 //   * spp > 1 (not in the reference except which==5, fs:654-673): sample s of
 //     n uses sub-pixel offset ((s+.5)/n, bitreverse32(s)*2^-32 + .5/n);
 //     linear radiance is summed in sample order, divided by n, then tone
@@ -128,6 +138,23 @@ inline float sr_pow5(float x)
     return (x2 * x2) * x;
 }
 
+// log2(x) for finite x > 0: exponent + 2/ln2 * atanh((m-1)/(m+1)) by its odd series to z^9,
+// m in [1, 2); every step one fp32 operation (absolute error < 2e-6, ample for choosing and
+// blending mip levels)
+inline float sr_log2(float x)
+{
+    int e;
+    const float m = 2.0f * frexpf(x, &e);   // x = m * 2^(e-1), m in [1, 2)
+    const float z = (m - 1.0f) / (m + 1.0f);
+    const float z2 = z * z;
+    float p = 0.111111111f * z2;
+    p = (p + 0.142857143f) * z2;
+    p = (p + 0.2f) * z2;
+    p = (p + 0.333333333f) * z2;
+    p = (p + 1.0f) * z;
+    return (float)(e - 1) + 2.88539008f * p;
+}
+
 // mat4 * vec4(v, w), column-major storage
 inline vec3 transform(const float m[16], vec3 v, float w)
 {
@@ -175,7 +202,37 @@ struct Scene {
     const float *boxmin, *boxmax, *hitmiss, *objects;
     const float *env;
     int env_w, env_h;
+    // mip pyramid of the environment (level 0 = env itself), built on demand for which == 1
+    std::vector<std::vector<float>> mip;
+    std::vector<int> mip_w, mip_h;
 };
+
+void build_mips(Scene &sc)
+{
+    sc.mip.clear();
+    sc.mip_w.assign(1, sc.env_w);
+    sc.mip_h.assign(1, sc.env_h);
+    sc.mip.emplace_back(sc.env, sc.env + 3 * (size_t)sc.env_w * sc.env_h);
+    while (sc.mip_w.back() > 1 || sc.mip_h.back() > 1) {
+        const int sw = sc.mip_w.back(), sh = sc.mip_h.back();
+        const int w = std::max(1, sw / 2), h = std::max(1, sh / 2);
+        const std::vector<float> &src = sc.mip.back();
+        std::vector<float> dst(3 * (size_t)w * h);
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const int i0 = std::min(2 * i, sw - 1), i1 = std::min(2 * i + 1, sw - 1);
+                const int j0 = std::min(2 * j, sh - 1), j1 = std::min(2 * j + 1, sh - 1);
+                for (int c = 0; c < 3; c++) {
+                    const float a = src[3 * ((size_t)j0 * sw + i0) + c], b = src[3 * ((size_t)j0 * sw + i1) + c];
+                    const float cc = src[3 * ((size_t)j1 * sw + i0) + c], d = src[3 * ((size_t)j1 * sw + i1) + c];
+                    dst[3 * ((size_t)j * w + i) + c] = ((a + b) + (cc + d)) * 0.25f;
+                }
+            }
+        sc.mip.push_back(std::move(dst));
+        sc.mip_w.push_back(w);
+        sc.mip_h.push_back(h);
+    }
+}
 
 struct Counters {
     uint64_t node_visits = 0, leaf_visits = 0, triangle_tests = 0, shaded_hits = 0, env_lookups = 0, traversals = 0,
@@ -445,7 +502,7 @@ int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3
 
     // ray_transfer fs:65-81, ray_reflect fs:83-96.  P and D do not depend on the differentials;
     // the differentials are only carried when a view needs them (which == 2)
-    if (p.which == 2) {
+    if (p.which == 1 || p.which == 2) {
         reflected = ray_reflect(ray_transfer(worldray, shading.t, world_normal), world_normal);
     } else {
         reflected = make_ray(worldray.P + worldray.D * shading.t + world_normal * .0001f, reflect(worldray.D, world_normal));
@@ -457,21 +514,10 @@ int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3
     return 1;
 }
 
-// fs:127-155, which == 0 branch: level-0 bilinear, REPEAT
-vec3 sample_environment(Ctx &cx, const ray &r)
+// LINEAR lookup with REPEAT wrap in one level of the environment at texture coordinates (s, t)
+vec3 bilinear_level(const float *texels, int w, int h, float s, float t)
 {
-    cx.c.env_lookups++;
-    const Scene &sc = *cx.scene;
-    if (cx.p->which == 2) {   // fs:135-149: draw the dY differential of the lookup coordinates
-        const float two_pi_rxz = 2.0f * pi * (r.D.x * r.D.x + r.D.z * r.D.z);
-        const float dudy = (r.D.x * r.dDdy.z - r.D.z * r.dDdy.x) / two_pi_rxz;
-        const float dvdy = r.dDdy.y / (pi * sqrtf(1.0f - r.D.y * r.D.y));
-        return V(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
-    }
-    const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
-    const float s = 1.0f + sr_atan2(-r.D.z, r.D.x) / tau;
-    const float t = 1.0f - sr_acos(dy) / pi;
-    const float fw = (float)sc.env_w, fh = (float)sc.env_h;
+    const float fw = (float)w, fh = (float)h;
     const float u = s * fw - 0.5f;
     const float v = t * fh - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
@@ -480,14 +526,79 @@ vec3 sample_environment(Ctx &cx, const ray &r)
         int i = (int)f % n;
         return i < 0 ? i + n : i;
     };
-    const int i0 = wrap(fu, sc.env_w), i1 = wrap(fu + 1.0f, sc.env_w);
-    const int j0 = wrap(fv, sc.env_h), j1 = wrap(fv + 1.0f, sc.env_h);
+    const int i0 = wrap(fu, w), i1 = wrap(fu + 1.0f, w);
+    const int j0 = wrap(fv, h), j1 = wrap(fv + 1.0f, h);
     auto texel = [&](int i, int j) {
-        const float *px = sc.env + 3 * ((size_t)j * sc.env_w + i);
+        const float *px = texels + 3 * ((size_t)j * w + i);
         return V(px[0], px[1], px[2]);
     };
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     return texel(i0, j0) * w00 + texel(i1, j0) * w10 + texel(i0, j1) * w01 + texel(i1, j1) * w11;
+}
+
+// one probe of the filtered lookup at level-of-detail lambda (see the header)
+vec3 trilinear_probe(const Scene &sc, float s, float t, float lambda)
+{
+    const int last = (int)sc.mip.size() - 1;
+    if (!(lambda > 0.0f))
+        return bilinear_level(sc.mip[0].data(), sc.mip_w[0], sc.mip_h[0], s, t);
+    if (lambda >= (float)last)
+        return bilinear_level(sc.mip[last].data(), sc.mip_w[last], sc.mip_h[last], s, t);
+    const float fl = floorf(lambda);
+    const int d1 = (int)fl;
+    const float f = lambda - fl;
+    const vec3 lo = bilinear_level(sc.mip[d1].data(), sc.mip_w[d1], sc.mip_h[d1], s, t);
+    const vec3 hi = bilinear_level(sc.mip[d1 + 1].data(), sc.mip_w[d1 + 1], sc.mip_h[d1 + 1], s, t);
+    return lo * (1.0f - f) + hi * f;
+}
+
+// textureGrad(sampler, (s, t), (dudx, dvdx), (dudy, dvdy)) as fixed in the header
+vec3 texture_grad(const Scene &sc, float s, float t, float dudx, float dvdx, float dudy, float dvdy)
+{
+    const float fw = (float)sc.env_w, fh = (float)sc.env_h;
+    const float ax = dudx * fw, ay = dvdx * fh, bx = dudy * fw, by = dvdy * fh;
+    const float px = sqrtf(ax * ax + ay * ay), py = sqrtf(bx * bx + by * by);
+    const float pmax = gl_max(px, py), pmin = gl_min(px, py);
+    const int last = (int)sc.mip.size() - 1;
+    if (!(pmax <= 3.0e38f))   // infinite or NaN footprint: the coarsest level
+        return bilinear_level(sc.mip[last].data(), sc.mip_w[last], sc.mip_h[last], s, t);
+    if (!(pmax > 0.0f))       // zero footprint: plain magnification
+        return bilinear_level(sc.mip[0].data(), sc.mip_w[0], sc.mip_h[0], s, t);
+    float n = 4.0f;           // GL_TEXTURE_MAX_ANISOTROPY_EXT, ray.cpp:506
+    if (pmin > 0.0f)
+        n = gl_min(ceilf(pmax / pmin), 4.0f);
+    const float lambda = sr_log2(pmax / n);
+    const bool along_x = px >= py;
+    const float mu = along_x ? dudx : dudy, mv = along_x ? dvdx : dvdy;
+    vec3 sum = V(0, 0, 0);
+    const int probes = (int)n;
+    for (int i = 1; i <= probes; i++) {
+        const float o = (float)i / (n + 1.0f) - 0.5f;
+        sum = sum + trilinear_probe(sc, s + o * mu, t + o * mv, lambda);
+    }
+    return sum / n;
+}
+
+// fs:127-155
+vec3 sample_environment(Ctx &cx, const ray &r)
+{
+    cx.c.env_lookups++;
+    const Scene &sc = *cx.scene;
+    const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
+    const float s = 1.0f + sr_atan2(-r.D.z, r.D.x) / tau;
+    const float t = 1.0f - sr_acos(dy) / pi;
+    if (cx.p->which == 1 || cx.p->which == 2) {   // fs:135-142: derivatives of the lookup coordinates
+        const float two_pi_rxz = 2.0f * pi * (r.D.x * r.D.x + r.D.z * r.D.z);
+        const float dudx = (r.D.x * r.dDdx.z - r.D.z * r.dDdx.x) / two_pi_rxz;
+        const float dudy = (r.D.x * r.dDdy.z - r.D.z * r.dDdy.x) / two_pi_rxz;
+        const float pi_ryy = pi * sqrtf(1.0f - r.D.y * r.D.y);
+        const float dvdx = r.dDdx.y / pi_ryy;
+        const float dvdy = r.dDdy.y / pi_ryy;
+        if (cx.p->which == 2)   // fs:147-149: draw the dY differential
+            return V(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+        return texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);   // fs:144-146
+    }
+    return bilinear_level(sc.env, sc.env_w, sc.env_h, s, t);   // fs:150-154: zero gradients = level 0, LINEAR
 }
 
 // fs:552-582
@@ -551,7 +662,7 @@ ray primary_ray(const shray_frame_params &p, float u, float v)
     const vec3 eye_d = normalize(V(p.image_plane_width * (u - 0.5f), p.image_plane_width * (v - 0.5f) * p.aspect, -1.0f));
     ray world = ray_transform(make_ray(V(0, 0, 0), eye_d), p.camera_matrix, p.camera_normal_matrix);
     world.D = normalize(world.D);
-    if (p.which == 2 || p.which == 3)
+    if (p.which == 1 || p.which == 2 || p.which == 3)
         set_differentials(p, world);
     return world;
 }
@@ -653,8 +764,8 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
 {
     if (!desc || !env_rgb || !params || !rgba_out || width <= 0 || height <= 0 || spp <= 0 || env_w <= 0 || env_h <= 0)
         return -1;
-    if (params->which == 1 || ((params->which == 3 || params->which == 5) && spp != 1))
-        return -1;   // textureGrad view not implemented; the 3 / 5 views are per-pixel, not per-sample
+    if ((params->which == 3 || params->which == 5) && spp != 1)
+        return -1;   // the 3 / 5 views are per-pixel, not per-sample
     row_begin = std::max(0, row_begin);
     row_end = std::min(height, row_end);
 
@@ -674,6 +785,8 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
     scene.env = env_rgb;
     scene.env_w = env_w;
     scene.env_h = env_h;
+    if (params->which == 1)
+        build_mips(scene);
 
     int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     nthreads = std::max(1, std::min(nthreads, std::max(1, row_end - row_begin)));
@@ -722,6 +835,19 @@ float shray_oracle_half(float f) { return round_through_half(f); }
 float shray_oracle_atan2(float y, float x) { return sr_atan2(y, x); }
 float shray_oracle_acos(float x) { return sr_acos(x); }
 float shray_oracle_pow5(float x) { return sr_pow5(x); }
+float shray_oracle_log2(float x) { return sr_log2(x); }
+// textureGrad of a given image (KATs): out = rgb
+void shray_oracle_texture_grad(const float *rgb, int w, int h, float s, float t, float dudx, float dvdx, float dudy,
+                               float dvdy, float out[3])
+{
+    Scene sc;
+    sc.env = rgb;
+    sc.env_w = w;
+    sc.env_h = h;
+    build_mips(sc);
+    const vec3 v = texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
 void shray_oracle_schlick(const float cspec[3], const float v[3], const float r[3], float out[3])
 {
     const vec3 f = f_schlick_vr(V(cspec[0], cspec[1], cspec[2]), V(v[0], v[1], v[2]), V(r[0], r[1], r[2]));

@@ -286,10 +286,6 @@ int validate_params(const shray_frame_params *p, int width, int height, int spp)
                     p->struct_size, sizeof(shray_frame_params));
     if (width <= 0 || height <= 0 || spp <= 0 || width > 65536 || height > 65536 || spp > (1 << 20))
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad frame geometry %dx%d, %d spp", width, height, spp);
-    if (p->which == 1)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT,
-                    "which = 1 (environment lookup through textureGrad with mip-maps and 4x anisotropy, "
-                    "raytracer.es.fs:146) is not implemented; 0, 2, 3, 5 are");
     if ((p->which == 3 || p->which == 5) && spp != 1)
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "which = %d is a per-pixel view; spp must be 1", p->which);
     if (p->bounce_count < 0 || p->bounce_count > 64 || p->max_bvh_iterations < 1 || p->max_bvh_iterations > (1 << 24) ||
@@ -362,7 +358,7 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
-    const bool view = fr.which == 2 || fr.which == 3 || fr.which == 5;
+    const bool view = fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5;
     if (s->kernel_id == 2 && s->packed_ok && !view)
         e = launch_persistent(s->view, fr, d_out, d_counters, stream, s->stack_levels,
                               (unsigned int *)s->work_counter.p, s->resident_blocks);
@@ -533,7 +529,41 @@ int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width,
     if (!scene || !rgb || width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad environment (%p, %d x %d)", (const void *)rgb, width, height);
     HIP_TRY(hipSetDevice(scene->device));
-    HIP_TRY(scene->env.upload(rgb, (size_t)width * height * 12));
+    // level 0 followed by its mip chain (2x2 box filter, ((a+b)+(c+d))*0.25, dimensions max(1, n/2)),
+    // the pyramid the reference asks GL for with glGenerateMipmap (ray.cpp:509); only the which == 1
+    // view reads levels above 0
+    std::vector<float> pyramid(rgb, rgb + (size_t)width * height * 3);
+    SceneView &v = scene->view;
+    v.mip_levels = 0;
+    size_t level_start = 0;
+    int w = width, h = height;
+    for (;;) {
+        v.mip_offset[v.mip_levels] = (uint32_t)level_start;
+        v.mip_w[v.mip_levels] = w;
+        v.mip_h[v.mip_levels] = h;
+        v.mip_levels++;
+        if ((w == 1 && h == 1) || v.mip_levels == 16)
+            break;
+        const int nw = std::max(1, w / 2), nh = std::max(1, h / 2);
+        const size_t next_start = pyramid.size();
+        pyramid.resize(next_start + (size_t)nw * nh * 3);
+        const float *src = pyramid.data() + level_start;
+        float *dst = pyramid.data() + next_start;
+        for (int j = 0; j < nh; j++)
+            for (int i = 0; i < nw; i++) {
+                const int i0 = std::min(2 * i, w - 1), i1 = std::min(2 * i + 1, w - 1);
+                const int j0 = std::min(2 * j, h - 1), j1 = std::min(2 * j + 1, h - 1);
+                for (int c = 0; c < 3; c++) {
+                    const float a = src[3 * ((size_t)j0 * w + i0) + c], b = src[3 * ((size_t)j0 * w + i1) + c];
+                    const float cc = src[3 * ((size_t)j1 * w + i0) + c], d = src[3 * ((size_t)j1 * w + i1) + c];
+                    dst[3 * ((size_t)j * nw + i) + c] = ((a + b) + (cc + d)) * 0.25f;
+                }
+            }
+        level_start = next_start;
+        w = nw;
+        h = nh;
+    }
+    HIP_TRY(scene->env.upload(pyramid.data(), pyramid.size() * sizeof(float)));
     scene->view.env = (const float *)scene->env.p;
     scene->view.env_w = width;
     scene->view.env_h = height;

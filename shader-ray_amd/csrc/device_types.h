@@ -38,8 +38,13 @@ struct SceneView {
     uint32_t packed_root;
     uint32_t exact_div_ok;      // every box coordinate is 0 or in [2^-70, 2^60): exact_div.h applies
 
-    const float *env;   // RGB f32, row 0 = t = 0 (straight down)
+    const float *env;   // RGB f32, row 0 = t = 0 (straight down); level 0 of the pyramid below
     int32_t env_w, env_h;
+    // mip pyramid for the which == 1 view: level k+1 = 2x2 box filter of level k, down to 1x1;
+    // level k starts mip_offset[k] floats into env and is mip_w[k] x mip_h[k]
+    int32_t mip_levels;
+    uint32_t mip_offset[16];
+    int32_t mip_w[16], mip_h[16];
 };
 
 // Per-launch parameters: the frame block plus frame geometry and tiling.

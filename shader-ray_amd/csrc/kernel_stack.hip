@@ -42,7 +42,7 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
         return hipGetLastError();
     }
 #endif
-    const bool diff = fr.which == 2;   // only that view needs the ray differentials carried along
+    const bool diff = fr.which == 1 || fr.which == 2;   // only those views need the ray differentials carried along
     if (counters && diff)
         hipLaunchKernelGGL((trace_stack_kernel<true, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
     else if (counters)

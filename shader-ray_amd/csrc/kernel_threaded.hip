@@ -15,7 +15,7 @@ hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out
                            hipStream_t stream)
 {
     const dim3 grid(fr.total_patches), block(256);
-    const bool diff = fr.which == 2;
+    const bool diff = fr.which == 1 || fr.which == 2;
     if (counters && diff)
         hipLaunchKernelGGL((trace_threaded_kernel<true, true>), grid, block, 0, stream, sc, fr, out, counters);
     else if (counters)

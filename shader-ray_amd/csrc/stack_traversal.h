@@ -27,7 +27,10 @@ namespace shray {
 #define SHRAY_UNIFIED_WALK 0
 #endif
 // lanes still walking below which the node loop yields to the leaf stage (when lanes are parked)
-constexpr int kStackKeepWalking = 24;
+#ifndef SHRAY_KEEP_WALKING
+#define SHRAY_KEEP_WALKING 12
+#endif
+constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
 // parked lanes required before walk_stage spends instructions on a triangle step while others walk
 #ifndef SHRAY_MIN_PARKED
 #define SHRAY_MIN_PARKED 1

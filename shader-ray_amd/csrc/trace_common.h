@@ -116,31 +116,107 @@ __device__ __forceinline__ V3 interpolated_normal(const SceneView &sc, bool fp16
     return mk(n[0], n[1], n[2]) * bw + mk(n[3], n[4], n[5]) * bu + mk(n[6], n[7], n[8]) * bv;
 }
 
-// sample_environment, fs:127-155 with which == 0: level-0 bilinear, REPEAT wrap
-__device__ __forceinline__ V3 environment(const SceneView &sc, V3 d)
+// LINEAR lookup with REPEAT wrap in one level of the environment pyramid
+__device__ __forceinline__ V3 environment_level(const float *texels, int w, int h, float s, float t)
 {
-    const float tau = 2 * kPi;
-    const float dy = sel_min(sel_max(d.y, -1.0f), 1.0f);
-    const float s = 1.0f + atan_yx(-d.z, d.x) / tau;
-    const float t = 1.0f - acos_clamped(dy) / kPi;
-    const float u = s * (float)sc.env_w - 0.5f;
-    const float v = t * (float)sc.env_h - 0.5f;
+    const float u = s * (float)w - 0.5f;
+    const float v = t * (float)h - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
-    int i0 = (int)fu % sc.env_w, j0 = (int)fv % sc.env_h;
-    int i1 = (int)(fu + 1.0f) % sc.env_w, j1 = (int)(fv + 1.0f) % sc.env_h;
-    i0 += i0 < 0 ? sc.env_w : 0;
-    i1 += i1 < 0 ? sc.env_w : 0;
-    j0 += j0 < 0 ? sc.env_h : 0;
-    j1 += j1 < 0 ? sc.env_h : 0;
-    const float *r0 = sc.env + 3 * (size_t)j0 * sc.env_w;
-    const float *r1 = sc.env + 3 * (size_t)j1 * sc.env_w;
+    int i0 = (int)fu % w, j0 = (int)fv % h;
+    int i1 = (int)(fu + 1.0f) % w, j1 = (int)(fv + 1.0f) % h;
+    i0 += i0 < 0 ? w : 0;
+    i1 += i1 < 0 ? w : 0;
+    j0 += j0 < 0 ? h : 0;
+    j1 += j1 < 0 ? h : 0;
+    const float *r0 = texels + 3 * (size_t)j0 * w;
+    const float *r1 = texels + 3 * (size_t)j1 * w;
     const V3 t00 = mk(r0[3 * i0], r0[3 * i0 + 1], r0[3 * i0 + 2]);
     const V3 t10 = mk(r0[3 * i1], r0[3 * i1 + 1], r0[3 * i1 + 2]);
     const V3 t01 = mk(r1[3 * i0], r1[3 * i0 + 1], r1[3 * i0 + 2]);
     const V3 t11 = mk(r1[3 * i1], r1[3 * i1 + 1], r1[3 * i1 + 2]);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     return t00 * w00 + t10 * w10 + t01 * w01 + t11 * w11;
+}
+
+// lat-long lookup coordinates of a direction, fs:130
+__device__ __forceinline__ void lookup_coords(V3 d, float &s, float &t)
+{
+    const float dy = sel_min(sel_max(d.y, -1.0f), 1.0f);
+    s = 1.0f + atan_yx(-d.z, d.x) / (2 * kPi);
+    t = 1.0f - acos_clamped(dy) / kPi;
+}
+
+// sample_environment, fs:127-155 with which == 0: level-0 bilinear, REPEAT wrap
+__device__ __forceinline__ V3 environment(const SceneView &sc, V3 d)
+{
+    float s, t;
+    lookup_coords(d, s, t);
+    return environment_level(sc.env, sc.env_w, sc.env_h, s, t);
+}
+
+// log2 of a finite positive float as an explicit fp32 sequence (identical in the oracle):
+// exponent + 2/ln2 * atanh((m-1)/(m+1)) by its odd series to z^9, m in [1, 2)
+__device__ __forceinline__ float log2_explicit(float x)
+{
+    int e;
+    const float m = 2.0f * frexpf(x, &e);
+    const float z = (m - 1.0f) / (m + 1.0f);
+    const float z2 = z * z;
+    float p = 0.111111111f * z2;
+    p = (p + 0.142857143f) * z2;
+    p = (p + 0.2f) * z2;
+    p = (p + 0.333333333f) * z2;
+    p = (p + 1.0f) * z;
+    return (float)(e - 1) + 2.88539008f * p;
+}
+
+__device__ __forceinline__ V3 pyramid_level(const SceneView &sc, int level, float s, float t)
+{
+    return environment_level(sc.env + sc.mip_offset[level], sc.mip_w[level], sc.mip_h[level], s, t);
+}
+
+// one probe at level-of-detail lambda: LINEAR at level 0 when magnifying, else the two nearest
+// levels blended by frac(lambda), clamped to the 1x1 level
+__device__ __forceinline__ V3 trilinear_probe(const SceneView &sc, float s, float t, float lambda)
+{
+    const int last = sc.mip_levels - 1;
+    if (!(lambda > 0.0f))
+        return pyramid_level(sc, 0, s, t);
+    if (lambda >= (float)last)
+        return pyramid_level(sc, last, s, t);
+    const float fl = floorf(lambda);
+    const int d1 = (int)fl;
+    const float f = lambda - fl;
+    return pyramid_level(sc, d1, s, t) * (1.0f - f) + pyramid_level(sc, d1 + 1, s, t) * f;
+}
+
+// textureGrad on the mip-mapped environment (fs:146; LINEAR_MIPMAP_LINEAR + 4x anisotropy,
+// ray.cpp:503-509) by the rule fixed in oracle/shader_oracle.cpp's header: GL 3.1 scale factors,
+// EXT_texture_filter_anisotropic's probe count / level / probe positions
+__device__ __forceinline__ V3 texture_grad(const SceneView &sc, float s, float t, float dudx, float dvdx, float dudy, float dvdy)
+{
+    const float fw = (float)sc.env_w, fh = (float)sc.env_h;
+    const float ax = dudx * fw, ay = dvdx * fh, bx = dudy * fw, by = dvdy * fh;
+    const float px = sqrtf(ax * ax + ay * ay), py = sqrtf(bx * bx + by * by);
+    const float pmax = sel_max(px, py), pmin = sel_min(px, py);
+    if (!(pmax <= 3.0e38f))
+        return pyramid_level(sc, sc.mip_levels - 1, s, t);
+    if (!(pmax > 0.0f))
+        return pyramid_level(sc, 0, s, t);
+    float n = 4.0f;
+    if (pmin > 0.0f)
+        n = sel_min(ceilf(pmax / pmin), 4.0f);
+    const float lambda = log2_explicit(pmax / n);
+    const bool along_x = px >= py;
+    const float mu = along_x ? dudx : dudy, mv = along_x ? dvdx : dvdy;
+    V3 sum = mk(0, 0, 0);
+    const int probes = (int)n;
+    for (int i = 1; i <= probes; i++) {
+        const float o = (float)i / (n + 1.0f) - 0.5f;
+        sum = sum + trilinear_probe(sc, s + mu * o, t + mv * o, lambda);
+    }
+    return sum / n;
 }
 
 // filmic, fs:527-531
@@ -181,13 +257,22 @@ __device__ __forceinline__ void bounce_differentials(Differentials &df, V3 D, fl
     df.dDdy = mk(df.dDdy.x - sy, df.dDdy.y - sy, df.dDdy.z - sy);
 }
 
-// sample_environment with which == 2 (fs:135-149): |d(s,t)/dy| * 100 instead of a texel
-__device__ __forceinline__ V3 environment_dy_view(V3 D, const Differentials &df)
+// sample_environment when the ray carries differentials (fs:135-149): which == 2 draws
+// |d(s,t)/dy| * 100 instead of a texel, which == 1 looks the texel up through textureGrad
+__device__ __forceinline__ V3 environment_with_differentials(const SceneView &sc, const FrameView &fr, V3 D,
+                                                             const Differentials &df)
 {
     const float two_pi_rxz = 2.0f * kPi * (D.x * D.x + D.z * D.z);
+    const float dudx = (D.x * df.dDdx.z - D.z * df.dDdx.x) / two_pi_rxz;
     const float dudy = (D.x * df.dDdy.z - D.z * df.dDdy.x) / two_pi_rxz;
-    const float dvdy = df.dDdy.y / (kPi * sqrtf(1.0f - D.y * D.y));
-    return mk(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+    const float pi_ryy = kPi * sqrtf(1.0f - D.y * D.y);
+    const float dvdx = df.dDdx.y / pi_ryy;
+    const float dvdy = df.dDdy.y / pi_ryy;
+    if (fr.which == 2)
+        return mk(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+    float s, t;
+    lookup_coords(D, s, t);
+    return texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);
 }
 
 // get_environment_map_coords, fs:121-125
@@ -258,7 +343,7 @@ __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr
     if (COUNT)
         rc.env_lookups++;
     if (DIFF)
-        return accumulated + modulation * environment_dy_view(D, df);
+        return accumulated + modulation * environment_with_differentials(sc, fr, D, df);
     return accumulated + modulation * environment(sc, D);
 }
 

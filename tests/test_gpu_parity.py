@@ -229,9 +229,9 @@ def test_error_paths(pkg, gpu, bunny, env_sky):
     assert e.value.code == -7          # SHRAY_ERR_NO_ENVIRONMENT
     fresh.close()
     bad = params.copy()
-    bad.which = 1
+    bad.which = 5
     with pytest.raises(N.ShrayError) as e:
-        scene.render(bad, 32, 32, 1)
+        scene.render(bad, 32, 32, 4)     # the 5x5 reference view is per pixel: spp must be 1
     assert e.value.code == -1 and "which" in str(e.value)
     bad = params.copy()
     bad.struct_size = 12
@@ -379,9 +379,10 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("which,material", [(2, 0), (2, 6), (3, 0), (5, 0), (5, 6), (4, 0)])
+@pytest.mark.parametrize("which,material", [(1, 0), (1, 6), (2, 0), (2, 6), (3, 0), (5, 0), (5, 6), (4, 0)])
 def test_which_views(pkg, gpu, oracle_mod, bunny, env_sky, which, material):
-    """The shader's `which` views (raytracer.es.fs:27): 2 = differential of the environment lookup
+    """The shader's `which` views (raytracer.es.fs:27): 1 = environment through textureGrad (mip
+    pyramid, trilinear, 4x anisotropy) with the ray differentials, 2 = differential of the lookup
     carried through the bounces, 3 = the pixel's own differentials, 5 = 5x5 supersampled
     reference image; other values render like 0.  Bit-identical to the oracle, counters equal."""
     world, desc, scene = bunny
@@ -399,3 +400,22 @@ def test_which_views(pkg, gpu, oracle_mod, bunny, env_sky, which, material):
             scene.render(params, 112, 80, 2)      # per-pixel views: spp must be 1
         else:
             raise pkg._native.ShrayError(-1, "n/a")
+
+
+def test_filtered_environment_view_on_a_small_frame(pkg, gpu, oracle_mod, env_sky):
+    """which == 1 with footprints of several texels (a 40 x 24 frame over a 512-wide environment,
+    and the sharp `grid` environment): exercises trilinear blending, the 2/3/4-probe anisotropic
+    paths and the poles' non-finite derivatives; bit-identical to the oracle."""
+    import test_oracle_kat as kat
+    for env in (env_sky, pkg.scenes.environment_grid(256)):
+        for hand, zoom in ((kat.far_away_triangle(), 4.0), (single_leaf_scene(kat.mirror_quad()), 3.0)):
+            params = default_params(pkg, 40, 24, zoom=zoom, material=0)
+            params.which = 1
+            scene = pkg.Scene(hand.desc, env, device=0)
+            check_against_oracle(oracle_mod, scene, hand.desc, env, params, 40, 24, 1, "filtered environment view")
+            # straight up: camera rotated so that the centre of an odd frame looks along +y (D.x = D.z = 0)
+            params = default_params(pkg, 33, 33, zoom=zoom, material=0)
+            params.which = 1
+            params.camera_normal_matrix[:] = [1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1]
+            check_against_oracle(oracle_mod, scene, hand.desc, env, params, 33, 33, 1, "filtered view at the pole")
+            scene.close()

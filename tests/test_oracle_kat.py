@@ -382,7 +382,7 @@ def test_view_5_is_the_mean_of_25_rays(pkg, oracle_mod):
     assert np.allclose(a, b, rtol=1e-6)
 
 
-def test_other_which_values_render_like_0_and_1_is_rejected(pkg, oracle_mod):
+def test_other_which_values_render_like_0(pkg, oracle_mod):
     scene = single_leaf_scene(mirror_quad())
     env = pkg.scenes.environment_hdr_sky(64)
     p = default_params(pkg, 12, 12, zoom=3.0)
@@ -391,6 +391,119 @@ def test_other_which_values_render_like_0_and_1_is_rejected(pkg, oracle_mod):
         p.which = w
         img, _ = oracle_mod.render(scene.desc, env, p, 12, 12)
         assert np.array_equal(img, base)
+
+
+# ---- which == 1: textureGrad on the mip-mapped environment (fs:144-146, ray.cpp:503-509)
+
+def mips64(img):
+    levels = [img.astype(np.float64)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        a = levels[-1]
+        h, w = max(1, a.shape[0] // 2), max(1, a.shape[1] // 2)
+        j0 = np.minimum(2 * np.arange(h), a.shape[0] - 1); j1 = np.minimum(2 * np.arange(h) + 1, a.shape[0] - 1)
+        i0 = np.minimum(2 * np.arange(w), a.shape[1] - 1); i1 = np.minimum(2 * np.arange(w) + 1, a.shape[1] - 1)
+        levels.append((a[j0][:, i0] + a[j0][:, i1] + a[j1][:, i0] + a[j1][:, i1]) * 0.25)
+    return levels
+
+
+def bilinear64(level, s, t):
+    h, w, _ = level.shape
+    u, v = s * w - 0.5, t * h - 0.5
+    i0, j0 = int(np.floor(u)), int(np.floor(v))
+    a, b = u - i0, v - j0
+    px = lambda i, j: level[j % h, i % w]
+    return (1 - a) * (1 - b) * px(i0, j0) + a * (1 - b) * px(i0 + 1, j0) + (1 - a) * b * px(i0, j0 + 1) + a * b * px(i0 + 1, j0 + 1)
+
+
+def texture_grad64(img, s, t, dudx, dvdx, dudy, dvdy, max_aniso=4):
+    """GL 3.1 section 3.8.9 + EXT_texture_filter_anisotropic reference formulas, in float64."""
+    levels = mips64(img)
+    h, w, _ = img.shape
+    px, py = np.hypot(dudx * w, dvdx * h), np.hypot(dudy * w, dvdy * h)
+    pmax, pmin = max(px, py), min(px, py)
+    if not np.isfinite(pmax):
+        return bilinear64(levels[-1], s, t)
+    if pmax == 0:
+        return bilinear64(levels[0], s, t)
+    n = max_aniso if pmin == 0 else min(np.ceil(pmax / pmin), max_aniso)
+    lam = np.log2(pmax / n)
+    mu, mv = (dudx, dvdx) if px >= py else (dudy, dvdy)
+    acc = np.zeros(3)
+    for i in range(1, int(n) + 1):
+        o = i / (n + 1) - 0.5
+        ss, tt = s + o * mu, t + o * mv
+        if lam <= 0:
+            acc += bilinear64(levels[0], ss, tt)
+        elif lam >= len(levels) - 1:
+            acc += bilinear64(levels[-1], ss, tt)
+        else:
+            d = int(np.floor(lam)); f = lam - d
+            acc += (1 - f) * bilinear64(levels[d], ss, tt) + f * bilinear64(levels[d + 1], ss, tt)
+    return acc / n
+
+
+def test_log2_sequence(oracle_mod):
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([10.0 ** rng.uniform(-6, 6, 3000), [1.0, 2.0, 0.5, 1024.0, 1.9999999, 1.0000001]])
+    for x in xs:
+        x = float(np.float32(x))
+        assert abs(oracle_mod.log2(x) - np.log2(np.float64(x))) < 4e-6, x
+    assert oracle_mod.log2(1.0) == 0.0 and oracle_mod.log2(8.0) == 3.0 and oracle_mod.log2(0.25) == -2.0
+
+
+def test_texture_grad_cases(oracle_mod):
+    rng = np.random.default_rng(4)
+    img = rng.uniform(0, 3, (16, 32, 3)).astype(np.float32)
+    W, H = 32, 16
+    cases = {
+        "zero gradients = level 0, LINEAR": (0.37, 0.61, 0, 0, 0, 0),
+        "sub-texel footprint magnifies": (0.37, 0.61, 0.5 / W, 0, 0, 0.25 / H),
+        "isotropic 2-texel footprint = level 1": (0.21, 0.43, 2.0 / W, 0, 0, 2.0 / H),
+        "lambda 1.5 blends levels 1 and 2": (0.71, 0.13, 2 ** 1.5 / W, 0, 0, 2 ** 1.5 / H),
+        "8:1 anisotropy: 4 probes at level 1": (0.55, 0.52, 8.0 / W, 0, 0, 1.0 / H),
+        "anisotropic along y, oblique": (0.30, 0.80, 0.3 / W, 0.2 / H, 2.0 / W, 5.0 / H),
+        "3:1 anisotropy: 3 probes": (0.10, 0.90, 6.0 / W, 0, 0, 2.0 / H),
+        "huge footprint = 1x1 level": (0.4, 0.4, 1000.0, 0, 0, 1000.0),
+        "degenerate (one zero axis)": (0.4, 0.4, 4.0 / W, 0, 0, 0),
+    }
+    for what, (s, t, dudx, dvdx, dudy, dvdy) in cases.items():
+        got = oracle_mod.texture_grad(img, s, t, dudx, dvdx, dudy, dvdy)
+        want = texture_grad64(img, s, t, dudx, dvdx, dudy, dvdy)
+        assert np.allclose(got, want, rtol=3e-5, atol=1e-5), (what, got, want)
+    # non-finite derivatives (straight up / down): the coarsest level = the mean of the image
+    got = oracle_mod.texture_grad(img, 0.5, 0.5, np.inf, 0, 0, 1.0)
+    assert np.allclose(got, img.reshape(-1, 3).mean(0), rtol=1e-5)
+    got = oracle_mod.texture_grad(img, 0.5, 0.5, np.nan, 0, 0, 1.0)
+    assert np.allclose(got, img.reshape(-1, 3).mean(0), rtol=1e-5)
+    flat = np.full((8, 8, 3), 0.75, np.float32)
+    assert np.allclose(oracle_mod.texture_grad(flat, 0.3, 0.3, 0.4, 0.1, -0.2, 0.3), 0.75, rtol=1e-6)
+
+
+def test_view_1_filters_the_environment_with_the_ray_differentials(pkg, oracle_mod):
+    """which == 1 end to end on environment-only pixels: derivatives of fs:135-139 from the
+    differentials of fs:621-625 into the textureGrad rule above; one pixel step is about one
+    texel at these sizes, so the view must stay close to the unfiltered one."""
+    W, H = 48, 27
+    env = pkg.scenes.environment_hdr_sky(128)
+    p = default_params(pkg, W, H)
     p.which = 1
-    with pytest.raises(RuntimeError):
-        oracle_mod.render(scene.desc, env, p, 12, 12)
+    img, c = oracle_mod.render(far_away_triangle().desc, env, p, W, H)
+    assert c["env_lookups"] == W * H
+    for (px, py) in ((3, 4), (40, 20), (24, 13), (10, 25)):
+        d = pixel_dir64(p, px, py, W, H)
+        ddx, ddy = differentials64(p, d)
+        rxz = 2 * np.pi * (d[0] ** 2 + d[2] ** 2)
+        dudx, dudy = (d[0] * ddx[2] - d[2] * ddx[0]) / rxz, (d[0] * ddy[2] - d[2] * ddy[0]) / rxz
+        ryy = np.pi * np.sqrt(1 - d[1] ** 2)
+        dvdx, dvdy = ddx[1] / ryy, ddy[1] / ryy
+        st = coords64(d)
+        want = filmic64(texture_grad64(env, st[0], st[1], dudx, dvdx, dudy, dvdy))
+        assert np.allclose(img[py, px, :3], want, rtol=2e-4, atol=2e-5), (px, py)
+    # a bigger frame of the same view = sub-texel footprints = level 0 (a few probes when the
+    # footprint is anisotropic): practically the unfiltered view
+    p2 = default_params(pkg, 960, 540)
+    p2.which = 1
+    a, _ = oracle_mod.render(far_away_triangle().desc, env, p2, 960, 540, rows=(100, 102))
+    p2.which = 0
+    b, _ = oracle_mod.render(far_away_triangle().desc, env, p2, 960, 540, rows=(100, 102))
+    assert np.allclose(a[100:102], b[100:102], rtol=2e-3, atol=1e-4)

@@ -98,9 +98,10 @@ typedef struct shray_scene_desc {
 typedef struct shray_frame_params {
     uint32_t struct_size;            /* sizeof(shray_frame_params) */
 
-    int32_t which;                   /* ray.cpp:648; 0 = normal rendering; 2, 3, 5 = the shader's debug /
-                                        reference views (raytracer.es.fs:147-149, :642-650, :654-673);
-                                        1 (textureGrad view) is rejected; other values render like 0 */
+    int32_t which;                   /* ray.cpp:648; 0 = normal rendering; 1 = environment through
+                                        textureGrad with the ray differentials (raytracer.es.fs:144-146),
+                                        2, 3 = differential debug views (:147-149, :642-650), 5 = 5x5
+                                        supersampled reference image (:654-673); others render like 0 */
 
     float camera_matrix[16];         /* ray.cpp:654 */
     float camera_normal_matrix[16];  /* ray.cpp:655 */

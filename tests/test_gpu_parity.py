@@ -419,3 +419,42 @@ def test_filtered_environment_view_on_a_small_frame(pkg, gpu, oracle_mod, env_sk
             params.camera_normal_matrix[:] = [1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1]
             check_against_oracle(oracle_mod, scene, hand.desc, env, params, 33, 33, 1, "filtered view at the pole")
             scene.close()
+
+
+def test_config3_64spp_plaster_band(pkg, gpu, oracle_mod, bunny, env_sky):
+    """BASELINE config 3 at full size (1920x1080, 64 spp, glazed plaster: shadow rays, up to six
+    traversals per sample): kernel 0 == kernel 1 bit for bit, and a band of rows equals the oracle."""
+    world, desc, scene = bunny
+    W, H, spp = 1920, 1080, 64
+    params = world.frame_params(W, H, material=6)
+    scene.set_kernel(0)
+    a = scene.render(params, W, H, spp)
+    rows = (300, 304)
+    want, _ = oracle_mod.render(desc, env_sky, params, W, H, spp, rows=rows)
+    assert np.array_equal(a[rows[0]:rows[1]].view(np.uint32), want[rows[0]:rows[1]].view(np.uint32))
+    scene.set_kernel(1)
+    b = scene.render(params, W, H, 4)      # the literal kernel at 4 spp (it is ~1.4x slower)
+    scene.set_kernel(0)
+    assert np.array_equal(b, scene.render(params, W, H, 4))
+    assert np.all(a[..., 3] == 1.0) and not np.isnan(a).any()
+
+
+def test_config5_4k_16spp_eight_way_tile_split(pkg, gpu, bunny):
+    """BASELINE config 5's frame (3840x2160, 16 spp) split into the eight interleaved tile sets the
+    eight GPUs would own: the packed tile buffers reassemble to the single-GPU frame bit for bit."""
+    import torch
+    from shader_ray_amd.multigpu import assemble_tiles_torch, max_tiles_per_rank
+    world, desc, scene = bunny
+    W, H, spp, tile, ranks = 3840, 2160, 16, 32, 8
+    params = world.frame_params(W, H, material=0)
+    full = torch.empty(H * W * 4, dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.render_into(params, W, H, spp, full.data_ptr(), stream, None)
+    per_rank = max_tiles_per_rank(W, H, tile, tile, ranks)
+    gathered = torch.zeros(ranks, per_rank * tile * tile * 4, dtype=torch.float32, device="cuda:0")
+    N = pkg._native
+    for r in range(ranks):
+        scene.render_into(params, W, H, spp, gathered[r].data_ptr(), stream, N.TileSet(tile, tile, ranks, r))
+    frame = assemble_tiles_torch(gathered.view(ranks, per_rank, tile, tile, 4), W, H, tile, tile)
+    torch.cuda.synchronize()
+    assert torch.equal(frame.reshape(-1), full)

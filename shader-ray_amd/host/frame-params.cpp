@@ -74,6 +74,25 @@ void update_view_params(world_ptr w, float zoom, const float object_rotation[4],
                          w->object_normal_matrix, w->object_normal_inverse);
 }
 
+void drag_to_rotation(float dx, float dy, float rotation[4])
+{
+    // the reference scales by 10000 before the square root "to decrease chance of underflow"
+    const float dist = sqrt(dx * 10000 * dx * 10000 + dy * 10000 * dy * 10000) / 10000;
+    rotation[0] = M_PI * dist;
+    rotation[1] = dy / dist;
+    rotation[2] = dx / dist;
+    rotation[3] = 0.0f;
+}
+
+void trackball_motion(float prevrotation[4], float dx, float dy, float newrotation[4])
+{
+    if (dx != 0 || dy != 0) {
+        float drag[4];
+        drag_to_rotation(dx, dy, drag);
+        rotation_mult_rotation(prevrotation, drag, newrotation);
+    }
+}
+
 view_state default_view_state(const world_ptr &w)
 {
     view_state s;

@@ -33,6 +33,12 @@ vec3 compute_light_dir(const float light_rotation[4]);
 // Fills the six matrices of `w` (ray.cpp:162-173).
 void update_view_params(world_ptr w, float zoom, const float object_rotation[4], const vec3 &object_position);
 
+// Mouse-drag trackball of the reference's shell (ray.cpp:76-98): a drag by (dx, dy) in window
+// fractions becomes an axis-angle rotation (angle = pi * |drag|, axis = (dy, dx, 0) / |drag|),
+// composed onto the previous rotation.  dx = dy = 0 leaves `newrotation` untouched, as upstream.
+void drag_to_rotation(float dx, float dy, float rotation[4]);
+void trackball_motion(float prevrotation[4], float dx, float dy, float newrotation[4]);
+
 // Interactive state of the reference's shell with its start-up values.
 struct view_state {
     float fov;                  // radians

@@ -3,9 +3,14 @@
 // frame on the GPU and save it the way the 's' key does (color.ppm, ray.cpp:730-787).
 //
 //   shray_render model.{trisrc,obj} background [-o out.ppm] [-w W -h H] [-m material] [-d diffuse] [-s spp]
+//                [-n frames]   animate: drag the trackball a little every frame (object for the first
+//                              half, light for the second, cycling the material every 25 frames), render
+//                              `frames` frames, print the reference's benchmark histogram (the 'B' key,
+//                              ray.cpp:1096-1131: 10 buckets of frame time / fps) and save the last frame
 //
 // background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
 // (host/background.cpp; the reference decodes image files through FreeImagePlus).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +30,7 @@ int main(int argc, char **argv)
                         "background color can be floats as \"r, g, b\", \"grid\", or hex as \"rrggbb\"\n", argv[0]);
         return EXIT_FAILURE;
     }
-    int width = 512, height = 512, material = 0, diffuse = 0, spp = 1;
+    int width = 512, height = 512, material = 0, diffuse = 0, spp = 1, frames = 1;
     std::string out = "color.ppm";
     for (int i = 3; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "-o")) out = argv[i + 1];
@@ -34,6 +39,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-m")) material = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-d")) diffuse = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-s")) spp = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "-n")) frames = atoi(argv[i + 1]);
     }
 
     world_ptr world = load_world(argv[1]);
@@ -78,13 +84,41 @@ int main(int argc, char **argv)
     make_frame_params(world, view, width, height, &params);
 
     std::vector<float> rgba((size_t)width * height * 4);
-    const auto then = std::chrono::steady_clock::now();
-    if (shray_render(scene, &params, width, height, spp, rgba.data()) != SHRAY_OK) {
-        fprintf(stderr, "render failed: %s\n", shray_last_error());
-        return EXIT_FAILURE;
+    std::vector<float> frame_seconds;
+    for (int frame = 0; frame < std::max(frames, 1); frame++) {
+        if (frames > 1) {
+            // what a user dragging the mouse does (MotionCallback, ray.cpp:879-918): the object for
+            // the first half of the run, the light ('l' key) for the second; 'm' every 25 frames
+            float *target = (frame < frames / 2) ? view.object_rotation : view.light_rotation;
+            trackball_motion(target, 0.011f, 0.004f, target);
+            if (frame % 25 == 24)
+                view.which_material = (view.which_material + 1) % material_count;
+            make_frame_params(world, view, width, height, &params);
+        }
+        const auto then = std::chrono::steady_clock::now();
+        if (shray_render(scene, &params, width, height, spp, rgba.data()) != SHRAY_OK) {
+            fprintf(stderr, "render failed: %s\n", shray_last_error());
+            return EXIT_FAILURE;
+        }
+        frame_seconds.push_back(std::chrono::duration<float>(std::chrono::steady_clock::now() - then).count());
     }
-    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - then).count();
-    fprintf(stderr, "%dx%d, %d spp: %.3f ms including the copy to host\n", width, height, spp, seconds * 1e3);
+    if (frames <= 1) {
+        fprintf(stderr, "%dx%d, %d spp: %.3f ms including the copy to host\n", width, height, spp, frame_seconds[0] * 1e3);
+    } else {
+        // the reference's benchmark print-out (ray.cpp:1116-1131)
+        const float lo = *std::min_element(frame_seconds.begin(), frame_seconds.end());
+        const float hi = *std::max_element(frame_seconds.begin(), frame_seconds.end());
+        printf("%d frames:\n", frames);
+        const int buckets = 10;
+        for (int b = 0; b < buckets; b++) {
+            const float start = lo + (hi - lo) * b / buckets, end = lo + (hi - lo) * (b + 1) / buckets;
+            int count = 0;
+            for (float d : frame_seconds)
+                if (d >= start && (d < end || (b == buckets - 1 && d <= end)))
+                    count++;
+            printf("%.2f to %.2f ms, %.2f fps : %d\n", start * 1000.0, end * 1000.0, 1 / ((start + end) / 2.0), count);
+        }
+    }
 
     FILE *fp = fopen(out.c_str(), "wb");
     if (!fp) {

@@ -115,3 +115,27 @@ def test_generators_are_deterministic(pkg, tmp_path):
     assert np.array_equal(e1, e2) and e1.max() > 10.0 and e1.dtype == np.float32
     g = pkg.scenes.environment_grid(64)
     assert g.shape == (32, 64, 3) and g[0].min() == 1.0 and g[1, 1].max() == 0.0 and g[3, 8].min() == 1.0
+
+
+def test_trackball_rotation_matches_the_reference_formulas(pkg):
+    """drag_to_rotation / trackball_motion (ray.cpp:76-98) through the frame parameters: a drag
+    turns the object about (dy, dx, 0) by pi * |drag|; compared with numpy's axis-angle matrix."""
+    import ctypes as C
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lobed_528.trisrc")
+    world = pkg.World(golden)
+    view = world.default_view()
+    dx, dy = 0.03, -0.02
+    dist = np.hypot(dx, dy)
+    angle, axis = np.pi * dist, np.array([dy / dist, dx / dist, 0.0])
+    view.object_rotation[:] = [float(angle), float(axis[0]), float(axis[1]), 0.0]
+    fp = world.frame_params(64, 64, view)
+    m = np.array(fp.object_matrix[:], dtype=np.float64).reshape(4, 4).T     # column-major -> rows
+    c, s_, t = np.cos(angle), np.sin(angle), 1 - np.cos(angle)
+    x, y, z = axis
+    rot = np.array([[t * x * x + c, t * x * y - s_ * z, t * x * z + s_ * y],
+                    [t * x * y + s_ * z, t * y * y + c, t * y * z - s_ * x],
+                    [t * x * z - s_ * y, t * y * z + s_ * x, t * z * z + c]])
+    assert np.allclose(m[:3, :3], rot, atol=1e-6)
+    # the object matrix maps world to object space about the scene centre (ray.cpp:118-123)
+    assert np.allclose(np.array(fp.object_normal_inverse[:]).reshape(4, 4).T[:3, :3], rot.T, atol=1e-6)

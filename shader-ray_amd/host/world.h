@@ -22,22 +22,18 @@ struct camera {
 struct world {
     int triangle_count;
     triangle_set_ptr triangles;   // traced only through `root`
-
-    group *root;
+    group *root;                  // owned
 
     vec3 scene_center;
-    float scene_extent;   // diameter of the bounding sphere about scene_center
+    float scene_extent;           // diameter of the bounding sphere about scene_center
 
     camera cam;
     int xsub, ysub;
 
-    float camera_matrix[16];
-    float camera_normal_matrix[16];
-
-    float object_matrix[16];
-    float object_inverse[16];
-    float object_normal_matrix[16];
-    float object_normal_inverse[16];
+    // eye -> world, and the six world <-> object matrices the shader receives (column-major)
+    float camera_matrix[16], camera_normal_matrix[16];
+    float object_matrix[16], object_inverse[16];
+    float object_normal_matrix[16], object_normal_inverse[16];
 
     world();
     ~world();
@@ -63,22 +59,17 @@ void set_trace_environment(const float *rgb, int width, int height);   // [heigh
 // out (world.h:68-93, world.cpp:298-347).  All float32; every array is padded
 // to data_texture_width * rows elements (padding is zero here).
 struct scene_shader_data {
-    unsigned int vertex_count;
-    unsigned int vertex_data_rows;
-    float *vertex_positions;   // float3 per vertex, three vertices per triangle
-    float *vertex_colors;      // float3
-    float *vertex_normals;     // float3
+    // per-triangle vertex attributes: float3 per vertex, three vertices per triangle
+    unsigned int vertex_count, vertex_data_rows;
+    float *vertex_positions, *vertex_colors, *vertex_normals;
 
-    int group_count;
-    int group_data_rows;
-    int tree_root;
-    float *group_boxmin;       // float3 per node
-    float *group_boxmax;       // float3 per node
-    float *group_directions;   // float3 per node (branches only)
-    float *group_children;     // float2 per node; 2147483648 for leaves
-
-    float *group_hitmiss;      // 8 tables of float2 (hit, miss); 2147483648 terminates
-    float *group_objects;      // float2 per node (start, count); 0,0 for branches
+    // per-node arrays, in-order node numbering
+    int group_count, group_data_rows, tree_root;
+    float *group_boxmin, *group_boxmax;   // float3
+    float *group_directions;              // float3, branches only
+    float *group_children;                // float2; 2147483648 for leaves
+    float *group_hitmiss;                 // 8 tables of float2 (hit, miss); 2147483648 terminates
+    float *group_objects;                 // float2 (start, count); 0,0 for branches
 
     scene_shader_data();
     ~scene_shader_data();

@@ -85,10 +85,20 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     # SHRAY_FORCE_DIST=1 rehearses the multi-GPU code path (process group, barrier, gather) with one rank
     distributed = world_size > 1 or os.environ.get("SHRAY_FORCE_DIST") == "1"
+    # Rehearsal on a single-GPU box: SHRAY_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # SHRAY_BENCH_BACKEND=gloo swaps RCCL (which refuses two ranks on one GPU) for gloo, staging the
+    # gather through host memory.  Only the control flow is rehearsed that way, never a reported number.
+    one_gpu = os.environ.get("SHRAY_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("SHRAY_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     pkg = load_package()
     # rank 0 generates the scene file once; the others wait for it
@@ -117,7 +127,8 @@ def main():
     lanes = max(1, args.frames_in_flight)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = [torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
-    splits = [multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device, always_gather=True) for _ in range(lanes)] if distributed else None
+    splits = [multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device, always_gather=True,
+                                        stage_through_host=(backend != "nccl")) for _ in range(lanes)] if distributed else None
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -154,6 +165,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if distributed and os.environ.get("SHRAY_BENCH_CHECK") == "1":
+        # rehearsal aid (every rank takes part in the extra frame): the assembled frame must equal
+        # a single-GPU render of the whole frame
+        last = step(args.steps)
+        torch.cuda.synchronize()
+        if rank == 0:
+            whole = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
+            scene.render_into(params, WIDTH, HEIGHT, SPP, whole.data_ptr(), torch.cuda.current_stream().cuda_stream, None)
+            torch.cuda.synchronize()
+            log("assembled frame equals the single-GPU frame:", bool(torch.equal(last.reshape(-1), whole)))
 
     result = None
     if rank == 0:

@@ -617,6 +617,9 @@ int shray_render_device(shray_scene *scene, const shray_frame_params *params, in
     rc = make_frame_view(params, width, height, spp, tiles, &fr);
     if (rc)
         return rc;
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != scene->device)
+        HIP_TRY(hipSetDevice(scene->device));   // the scene's buffers and the stream live on its device
     return launch(scene, fr, (float4 *)d_rgba_out, nullptr, (hipStream_t)hip_stream);
 }
 

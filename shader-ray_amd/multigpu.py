@@ -68,12 +68,13 @@ class DistributedFrame:
     frame is: render -> gather -> one permute/crop kernel.  Nothing synchronises with the host."""
 
     def __init__(self, width: int, height: int, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE, group=None,
-                 device=None, always_gather: bool = False):
+                 device=None, always_gather: bool = False, stage_through_host: bool = False):
         import torch
         import torch.distributed as dist
         self.width, self.height, self.tile_w, self.tile_h = width, height, tile_w, tile_h
         self.group = group
         self.always_gather = always_gather   # run the collective even with one rank (rehearsal)
+        self.stage_through_host = stage_through_host   # gloo rehearsal: the collective moves host copies
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, self.world)
@@ -95,7 +96,15 @@ class DistributedFrame:
         if self.world == 1 and not self.always_gather:
             gathered = self.mine.view(1, self.per_rank, self.tile_h, self.tile_w, 4)
             return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
-        dist.gather(self.mine, self.sink, dst=0, group=self.group)
+        if self.stage_through_host:
+            mine_host = self.mine.cpu()
+            sink_host = [t.cpu() for t in self.sink] if self.rank == 0 else None
+            dist.gather(mine_host, sink_host, dst=0, group=self.group)
+            if self.rank == 0:
+                for dst, src in zip(self.sink, sink_host):
+                    dst.copy_(src)
+        else:
+            dist.gather(self.mine, self.sink, dst=0, group=self.group)
         if self.rank != 0:
             return None
         gathered = self.received.view(self.world, self.per_rank, self.tile_h, self.tile_w, 4)

@@ -68,7 +68,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="independent frames alternate over this many HIP streams (1 = strictly one frame at a time)")
+                    help="independent frames (N > 1: launches) alternate over this many HIP streams (1 = strictly one at a time)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="N > 1 only: consecutive frames a rank renders in one launch and sends in one gather "
+                         "(default: the number of GPUs, so a launch always carries one frame's worth of pixels per GPU)")
+    ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: gather RGBA instead of RGB (alpha is the constant 1)")
     args = ap.parse_args()
 
     import torch
@@ -125,21 +129,23 @@ def main():
     # fill frame k's tail -- and, with several GPUs, lets the gather of frame k overlap the render
     # of frame k+1.  Every frame is still rendered completely into its own buffer.
     lanes = max(1, args.frames_in_flight)
+    # N > 1: a rank's share of one 1080p frame is latency-bound (its long-running waves take ~0.5 ms
+    # wherever they land), so a launch carries `batch` consecutive frames (shray_render_batch_device) and
+    # one gather moves them all: fewer, larger collectives, and the GPU stays full.
+    batch = max(1, min(64, args.frames_per_launch or world_size)) if distributed else 1
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = [torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     splits = [multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device, always_gather=True,
-                                        stage_through_host=(backend != "nccl")) for _ in range(lanes)] if distributed else None
+                                        stage_through_host=(backend != "nccl"), frames=batch,
+                                        rgb_wire=not args.rgba_wire) for _ in range(lanes)] if distributed else None
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
 
     def step(k, timed=False):
+        """frame k, one launch (single-GPU path)"""
         lane = k % lanes
         st = streams[lane]
-        if distributed:
-            def render_tiles(tile_set, out):
-                scene.render_into(params, WIDTH, HEIGHT, SPP, out.data_ptr(), st.cuda_stream, tile_set)
-            with torch.cuda.stream(st):
-                return splits[lane].render(render_tiles)
         if timed:
             starts[k].record(st)
         scene.render_into(params, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
@@ -147,18 +153,43 @@ def main():
             stops[k].record(st)
         return frame_outs[lane]
 
+    def launch(j, count):
+        """`count` frames: this rank's tiles in one launch, one gather to rank 0, one de-interleave"""
+        lane = j % lanes
+        st = streams[lane]
+        split = splits[lane]
+
+        def render_tiles(tile_set, out):
+            scene.render_batch_into([params] * count, WIDTH, HEIGHT, SPP, out.data_ptr(), split.frame_stride_bytes,
+                                    st.cuda_stream, tile_set)
+        with torch.cuda.stream(st):
+            return split.render(render_tiles, count)
+
+    def run(frames, timed=False):
+        """exactly `frames` frames; returns what the last launch produced"""
+        last = None
+        if not distributed:
+            for k in range(frames):
+                last = step(k, timed)
+            return last
+        done = j = 0
+        while done < frames:
+            count = min(batch, frames - done)
+            last = launch(j, count)
+            done += count
+            j += 1
+        return last
+
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    run(args.warmup)
     fence()
 
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, timed=True)
+    run(args.steps, timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -167,15 +198,17 @@ def main():
         elapsed = float(t.item())
 
     if distributed and os.environ.get("SHRAY_BENCH_CHECK") == "1":
-        # rehearsal aid (every rank takes part in the extra frame): the assembled frame must equal
-        # a single-GPU render of the whole frame
-        last = step(args.steps)
+        # rehearsal aid (every rank takes part in the extra launch): every assembled frame must
+        # equal a single-GPU render of the whole frame
+        last = run(batch)
         torch.cuda.synchronize()
         if rank == 0:
             whole = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
             scene.render_into(params, WIDTH, HEIGHT, SPP, whole.data_ptr(), torch.cuda.current_stream().cuda_stream, None)
             torch.cuda.synchronize()
-            log("assembled frame equals the single-GPU frame:", bool(torch.equal(last.reshape(-1), whole)))
+            last = last if last.dim() == 4 else last.unsqueeze(0)
+            same = all(bool(torch.equal(last[f].reshape(-1), whole)) for f in range(last.shape[0]))
+            log(f"all {last.shape[0]} assembled frame(s) equal the single-GPU frame:", same)
 
     result = None
     if rank == 0:
@@ -189,8 +222,20 @@ def main():
                                    "2048x1024 HDR sky, 1920x1080, 1 spp, gold, 3 bounces (BASELINE configs[1])",
                        "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "persistent"}[args.kernel],
                        "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu",
-                       "frames_in_flight": lanes},
+                       "frames_in_flight": lanes * batch, "frames_per_launch": batch, "streams": lanes,
+                       "wire": ("rgb32f" if not args.rgba_wire else "rgba32f") if distributed else None},
         }
+    if distributed and rank == 0:
+        # all ranks together execute exactly the fetches of the whole frame: per-GPU algorithmic rate
+        _, counters = scene.render_counters(params, WIDTH, HEIGHT, SPP, want_image=False)
+        algo_bytes = pkg.tracer.algorithmic_bytes(counters, WIDTH * HEIGHT, normals_fp16=True)
+        per_gpu = algo_bytes * args.steps / elapsed / 1e9 / world_size
+        result["roofline"] = {"bound": "hbm", "achieved": round(per_gpu, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(per_gpu / HBM_PEAK_GBS, 5), "traffic": None,
+                              "algorithmic_bytes_per_frame": algo_bytes,
+                              "note": "per GPU, whole job: algorithmic bytes of the frames / wall time / n_gpus "
+                                      "(gather and de-interleave included in the time)"}
+        result["counters"] = counters
     if not distributed:
         # per-launch kernel time: HIP events recorded around every launch of the timed region, on
         # the stream that launch went to.  With frames_in_flight > 1 two launches share the GPU,

@@ -15,6 +15,9 @@
  *                           <- uniform block + glDrawArrays in DrawFrame,
  *                              ray.cpp:648-707, and the glReadPixels readback
  *                              in screenshot, ray.cpp:760
+ *   shray_render_batch_device
+ *                           <- the frame loop around DrawFrame (benchmark key,
+ *                              ray.cpp:1096-1131): several frames per launch
  *   shray_scene_destroy     <- (GL objects are never freed upstream)
  *
  * Plain C, plain pointers and sizes, no C++/torch types.  All matrices are
@@ -190,6 +193,31 @@ int shray_render_device(shray_scene *scene, const shray_frame_params *params,
                         void *d_rgba_out, void *hip_stream);
 
 int64_t shray_tile_buffer_bytes(int width, int height, const shray_tile_set *tiles);
+
+/* `count` consecutive frames (the DrawFrame loop of ray.cpp:1096-1131, or the frames of a
+ * camera animation) in ONE launch: frame k is rendered with params[k] into
+ * d_rgba_out + k * frame_stride_bytes, each frame laid out exactly as shray_render_device
+ * lays out its single frame.  The few long-running waves of a frame (rays grazing the
+ * silhouette) no longer leave the GPU idle: the next frames' work fills in behind them.
+ * 1 <= count <= SHRAY_MAX_BATCH; frame_stride_bytes is a multiple of 16 and at least
+ * shray_tile_buffer_bytes(); all frames must agree on whether `which` is a
+ * differential view (1 or 2) or not. */
+#define SHRAY_MAX_BATCH 64
+int shray_render_batch_device(shray_scene *scene, const shray_frame_params *params, int count,
+                              int width, int height, int spp,
+                              const shray_tile_set *tiles,
+                              void *d_rgba_out, int64_t frame_stride_bytes, void *hip_stream);
+
+/* Multi-GPU, rank 0: de-interleaves gathered tile buffers into whole frames (the inverse of
+ * shray_tile_set ownership).  d_gathered holds, for rank r = 0..world-1 and frame f = 0..frames-1,
+ * that rank's packed tiles at d_gathered + r * rank_stride_bytes + f * frame_stride_bytes, pixels
+ * as `channels` float32 (4 = RGBA as rendered; 3 = RGB, alpha having been dropped on the wire
+ * because it is the constant 1).  d_rgba_out receives `frames` RGBA frames of width * height
+ * pixels, back to back.  There is no upstream counterpart: one GPU, one framebuffer. */
+int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, int channels,
+                                int64_t rank_stride_bytes, int64_t frame_stride_bytes,
+                                int width, int height, int tile_w, int tile_h,
+                                void *d_rgba_out, void *hip_stream);
 
 /* Same render with per-ray work counters accumulated (slower; used for the
  * roofline's algorithmic-byte count and for parity of the traversal itself). */

@@ -10,7 +10,8 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB = os.path.join(PKG_DIR, "libshray_host.so")
-HIP_LIB = os.path.join(PKG_DIR, "libshray_hip.so")
+# SHRAY_HIP_LIB selects an experiment build of the same library (profiles/variant_sweep.sh); unset in normal use
+HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -90,7 +91,11 @@ HIP_SYMBOLS = [
     ("shray_render", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, c_float_p]),
     ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
+    ("shray_render_batch_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(TileSet), C.c_void_p, C.c_int64, C.c_void_p]),
     ("shray_tile_buffer_bytes", C.c_int64, [C.c_int, C.c_int, C.POINTER(TileSet)]),
+    ("shray_assemble_tiles_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("shray_render_counters", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                         c_float_p, C.POINTER(Counters)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -112,7 +112,25 @@ struct shray_scene {
     DeviceBuffer patch_order;        // permutation of patch indices for the stack kernel (optional)
     uint32_t patch_order_count = 0;
 
+    // shray_render_batch_device: per-frame FrameViews travel through a small ring of slots
+    // (pinned staging -> device); a slot is reused only after the launch that read it has finished
+    static constexpr int kBatchSlots = 4;
+    FrameView *batch_staging = nullptr;   // pinned host, kBatchSlots * SHRAY_MAX_BATCH
+    DeviceBuffer batch_views;             // device, same shape
+    hipEvent_t batch_done[kBatchSlots] = {};
+    bool batch_pending[kBatchSlots] = {};
+    int batch_next = 0;
+
     SceneView view{};
+
+    ~shray_scene()
+    {
+        for (int k = 0; k < kBatchSlots; k++)
+            if (batch_done[k])
+                (void)hipEventDestroy(batch_done[k]);
+        if (batch_staging)
+            (void)hipHostFree(batch_staging);
+    }
 };
 
 namespace {
@@ -621,6 +639,99 @@ int shray_render_device(shray_scene *scene, const shray_frame_params *params, in
     if (hipGetDevice(&current) != hipSuccess || current != scene->device)
         HIP_TRY(hipSetDevice(scene->device));   // the scene's buffers and the stream live on its device
     return launch(scene, fr, (float4 *)d_rgba_out, nullptr, (hipStream_t)hip_stream);
+}
+
+int shray_render_batch_device(shray_scene *scene, const shray_frame_params *params, int count, int width, int height,
+                              int spp, const shray_tile_set *tiles, void *d_rgba_out, int64_t frame_stride_bytes,
+                              void *hip_stream)
+{
+    if (!scene || !d_rgba_out || !params)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene, params or output buffer is NULL");
+    if (count < 1 || count > SHRAY_MAX_BATCH)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "batch of %d frames (1..%d allowed)", count, SHRAY_MAX_BATCH);
+    if (!scene->view.env)
+        return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");
+    const int64_t frame_bytes = shray_tile_buffer_bytes(width, height, tiles);
+    if (frame_stride_bytes < frame_bytes || frame_stride_bytes % 16 != 0)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "frame_stride_bytes %lld must be a multiple of 16 and at least the %lld "
+                    "bytes of one frame", (long long)frame_stride_bytes, (long long)frame_bytes);
+    std::vector<FrameView> views((size_t)count);
+    for (int k = 0; k < count; k++) {
+        int rc = validate_params(params + k, width, height, spp);
+        if (rc)
+            return rc;
+        rc = make_frame_view(params + k, width, height, spp, tiles, &views[k]);
+        if (rc)
+            return rc;
+        const bool diff0 = views[0].which == 1 || views[0].which == 2, diffk = views[k].which == 1 || views[k].which == 2;
+        if (diff0 != diffk)
+            return fail(SHRAY_ERR_INVALID_ARGUMENT, "frames %d and 0 of a batch disagree on differential views "
+                        "(which = %d vs %d)", k, views[k].which, views[0].which);
+    }
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != scene->device)
+        HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    char *out = (char *)d_rgba_out;
+
+    // anything but the stack kernel (or a single frame) runs as plain consecutive launches
+    if (count == 1 || scene->kernel_id != 0 || !scene->packed_ok || scene->patch_order.p) {
+        for (int k = 0; k < count; k++) {
+            const int rc = launch(scene, views[k], (float4 *)(out + (size_t)k * frame_stride_bytes), nullptr, stream);
+            if (rc)
+                return rc;
+        }
+        return SHRAY_OK;
+    }
+    if (views[0].total_patches == 0)
+        return SHRAY_OK;
+
+    if (!scene->batch_staging) {
+        const size_t bytes = sizeof(FrameView) * shray_scene::kBatchSlots * SHRAY_MAX_BATCH;
+        HIP_TRY(hipHostMalloc((void **)&scene->batch_staging, bytes, hipHostMallocDefault));
+        HIP_TRY(scene->batch_views.upload(nullptr, bytes));
+        for (int k = 0; k < shray_scene::kBatchSlots; k++)
+            HIP_TRY(hipEventCreateWithFlags(&scene->batch_done[k], hipEventDisableTiming));
+    }
+    const int slot = scene->batch_next;
+    scene->batch_next = (slot + 1) % shray_scene::kBatchSlots;
+    if (scene->batch_pending[slot])
+        HIP_TRY(hipEventSynchronize(scene->batch_done[slot]));   // rarely waits: the launch four batches ago
+    FrameView *staged = scene->batch_staging + (size_t)slot * SHRAY_MAX_BATCH;
+    FrameView *d_views = (FrameView *)scene->batch_views.p + (size_t)slot * SHRAY_MAX_BATCH;
+    memcpy(staged, views.data(), sizeof(FrameView) * (size_t)count);
+    HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
+    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], (float4 *)d_rgba_out,
+                                            (size_t)frame_stride_bytes / 16, stream, scene->stack_levels);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
+    scene->batch_pending[slot] = true;
+    return SHRAY_OK;
+}
+
+int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, int channels, int64_t rank_stride_bytes,
+                                int64_t frame_stride_bytes, int width, int height, int tile_w, int tile_h,
+                                void *d_rgba_out, void *hip_stream)
+{
+    if (!d_gathered || !d_rgba_out)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "gathered or output buffer is NULL");
+    if (world < 1 || frames < 1 || frames > 65535 || (channels != 3 && channels != 4) || width <= 0 || height <= 0 ||
+        width > 65536 || height > 65535 || tile_w <= 0 || tile_h <= 0)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad assemble geometry (world %d, %d frames, %d channels, %dx%d, tiles %dx%d)",
+                    world, frames, channels, width, height, tile_w, tile_h);
+    const int64_t tiles = (int64_t)((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+    const int64_t frame_bytes = (tiles + world - 1) / world * tile_w * tile_h * channels * 4;
+    if (frame_stride_bytes < frame_bytes || frame_stride_bytes % 4 || rank_stride_bytes % 4 ||
+        rank_stride_bytes < (int64_t)(frames - 1) * frame_stride_bytes + frame_bytes)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "strides too small: a rank's frame takes %lld bytes (frame stride %lld, "
+                    "rank stride %lld)", (long long)frame_bytes, (long long)frame_stride_bytes, (long long)rank_stride_bytes);
+    const hipError_t e = launch_assemble_tiles((const float *)d_gathered, (float4 *)d_rgba_out, world, frames, channels, width,
+                                               height, tile_w, tile_h, (size_t)rank_stride_bytes / 4,
+                                               (size_t)frame_stride_bytes / 4, (hipStream_t)hip_stream);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return SHRAY_OK;
 }
 
 int shray_render(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,

@@ -31,6 +31,30 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES) trace_stack_kernel(Sc
     trace_pixels<StackTraversal<kBlock>, COUNT, DIFF>(sc, fr, out, counters, trav);
 }
 
+// Batch form: workgroup (x, y) renders patch x of frame y.  Workgroups are dispatched x-fastest, so
+// frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
+template <bool DIFF>
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+                                                                                   float4 *out, size_t frame_stride)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock> trav;
+    trav.stack = lds_stack + threadIdx.x;
+    trace_pixels<StackTraversal<kBlock>, false, DIFF>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
+}
+
+hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first,
+                              float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
+{
+    const dim3 grid(first.total_patches, (unsigned)count), block(kBlock);
+    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + SHRAY_LDS_PAD;
+    if (first.which == 1 || first.which == 2)
+        hipLaunchKernelGGL((trace_stack_batch_kernel<true>), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride);
+    else
+        hipLaunchKernelGGL((trace_stack_batch_kernel<false>), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
                         hipStream_t stream, int stack_levels)
 {

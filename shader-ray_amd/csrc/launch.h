@@ -18,6 +18,17 @@ hipError_t launch_threaded(const SceneView &sc, const FrameView &fr, float4 *out
 hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
                         hipStream_t stream, int stack_levels);
 
+// `count` frames in one launch (grid.y = frame): d_frames[k] is frame k's view, written to
+// out + k * frame_stride (in float4 units); `first` is frame 0's view (grid shape, differential class)
+hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first,
+                              float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
+
+// rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,
+// frame_stride between a rank's consecutive frames
+hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, int frames, int channels, int width,
+                                 int height, int tile_w, int tile_h, size_t rank_stride, size_t frame_stride,
+                                 hipStream_t stream);
+
 // persistent kernel: `work_counter` is one uint in device memory (zeroed on the stream before
 // the launch), `resident_blocks` the number of 256-thread workgroups the device keeps resident
 hipError_t launch_persistent(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,

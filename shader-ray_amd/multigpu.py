@@ -7,8 +7,15 @@ index % world_size == r (interleaved, because the object sits mid-frame and cont
 bands would be unbalanced) and packs them densely; one gather of the packed tile buffers to
 rank 0 (RCCL over xGMI: every peer sends on its own link) is the only exchange step; rank 0
 de-interleaves.  Samples of a pixel never leave their GPU, so there is no reduction.
+
+Frames per step: a rank's share of ONE 1080p frame is latency-bound -- the frame's few
+long-running waves take ~0.5 ms wherever they land, whatever the share (profiles/r01) -- so a
+step carries `frames` consecutive frames: one launch (shray_render_batch_device), one larger
+gather, one de-interleave.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
@@ -61,57 +68,104 @@ def max_tiles_per_rank(width: int, height: int, tile_w: int, tile_h: int, world:
 
 
 class DistributedFrame:
-    """One frame split across the ranks of a torch.distributed group, reusable across frames.
+    """`frames` consecutive frames split across the ranks of a torch.distributed group, reusable.
 
-    All buffers are allocated once: this rank's packed tile buffer and, on rank 0, one
-    [world, max_tiles, tile_h, tile_w, 4] receive buffer whose rows are the gather targets, so a
-    frame is: render -> gather -> one permute/crop kernel.  Nothing synchronises with the host."""
+    All buffers are allocated once: this rank's packed tile buffer ([frames, tiles, tile_h,
+    tile_w, 4], what the kernel writes), its wire buffer and, on rank 0, one [world, frames, ...]
+    receive buffer whose rows are the gather targets and the assembled [frames, height, width, 4]
+    output.  A step is: render (one launch for all `frames`) -> pack -> ONE gather -> one
+    permute/crop copy.  Nothing synchronises with the host.
+
+    Wire format: alpha is the constant 1 for every pixel of a frame (raytracer.es.fs:676), so
+    with `rgb_wire` only R, G, B travel (12 instead of 16 bytes per pixel over xGMI) and rank 0
+    writes them into an output whose alpha plane is already 1."""
 
     def __init__(self, width: int, height: int, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE, group=None,
-                 device=None, always_gather: bool = False, stage_through_host: bool = False):
+                 device=None, always_gather: bool = False, stage_through_host: bool = False, frames: int = 1,
+                 rgb_wire: bool = True):
         import torch
         import torch.distributed as dist
         self.width, self.height, self.tile_w, self.tile_h = width, height, tile_w, tile_h
         self.group = group
+        self.frames = frames
+        self.channels = 3 if rgb_wire else 4
         self.always_gather = always_gather   # run the collective even with one rank (rehearsal)
         self.stage_through_host = stage_through_host   # gloo rehearsal: the collective moves host copies
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, self.world)
-        n = self.per_rank * tile_h * tile_w * 4
-        self.mine = torch.zeros(n, dtype=torch.float32, device=device)
+        self.pixels = self.per_rank * tile_h * tile_w          # per frame, padded to whole tiles
+        self.mine = torch.zeros(frames, self.pixels * 4, dtype=torch.float32, device=device)
+        self.wire = torch.zeros(frames, self.pixels * 3, dtype=torch.float32, device=device) if rgb_wire else self.mine
         self.tiles = N.TileSet(tile_w, tile_h, self.world, self.rank)
         self.received = None
-        self.sink = None
+        self.output = None
         if self.rank == 0:
-            self.received = torch.zeros(self.world, n, dtype=torch.float32, device=device)
-            self.sink = [self.received[r] for r in range(self.world)]
+            self.received = torch.zeros(self.world, frames, self.pixels * self.channels, dtype=torch.float32, device=device)
+            self.output = torch.ones(frames, height, width, 4, dtype=torch.float32, device=device)
 
-    def render(self, render_tiles):
-        """`render_tiles(tile_set, out_tensor)` fills this rank's packed tiles (on a GPU box that
-        is Scene.render_into; the CPU rehearsal passes an oracle-backed stand-in).  Returns the
-        assembled [height, width, 4] frame on rank 0, None elsewhere."""
+    @property
+    def frame_stride_bytes(self) -> int:
+        return self.pixels * 16
+
+    def render(self, render_tiles, count: int | None = None):
+        """`render_tiles(tile_set, out_tensor)` fills this rank's packed tiles of `count` (default:
+        all `frames`) frames, frame k at out_tensor[k] (on a GPU box that is
+        Scene.render_batch_into; the CPU rehearsal passes an oracle-backed stand-in).  Returns the
+        assembled frames on rank 0 -- [height, width, 4] when the object holds one frame, else
+        [count, height, width, 4] -- and None elsewhere."""
         import torch.distributed as dist
-        render_tiles(self.tiles, self.mine)
+        count = self.frames if count is None else count
+        assert 1 <= count <= self.frames
+        mine = self.mine[:count]
+        render_tiles(self.tiles, mine)
+        wire = mine
+        if self.channels == 3:
+            wire = self.wire[:count]
+            wire.view(count, self.pixels, 3).copy_(mine.view(count, self.pixels, 4)[:, :, :3])
         if self.world == 1 and not self.always_gather:
-            gathered = self.mine.view(1, self.per_rank, self.tile_h, self.tile_w, 4)
-            return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
+            return self._assemble(wire.unsqueeze(0), count)
+        sink = [self.received[r, :count] for r in range(self.world)] if self.rank == 0 else None
         if self.stage_through_host:
-            mine_host = self.mine.cpu()
-            sink_host = [t.cpu() for t in self.sink] if self.rank == 0 else None
-            dist.gather(mine_host, sink_host, dst=0, group=self.group)
+            wire_host = wire.cpu()
+            sink_host = [t.cpu() for t in sink] if self.rank == 0 else None
+            dist.gather(wire_host, sink_host, dst=0, group=self.group)
             if self.rank == 0:
-                for dst, src in zip(self.sink, sink_host):
+                for dst, src in zip(sink, sink_host):
                     dst.copy_(src)
         else:
-            dist.gather(self.mine, self.sink, dst=0, group=self.group)
+            dist.gather(wire, sink, dst=0, group=self.group)
         if self.rank != 0:
             return None
-        gathered = self.received.view(self.world, self.per_rank, self.tile_h, self.tile_w, 4)
-        return assemble_tiles_torch(gathered, self.width, self.height, self.tile_w, self.tile_h)
+        return self._assemble(self.received[:, :count], count)
+
+    def _assemble(self, gathered, count: int):
+        """gathered: [world, count, pixels * channels], rank-major as gathered."""
+        import torch
+        c = self.channels
+        if self.output is None:   # world == 1 without a process group
+            self.output = torch.ones(self.frames, self.height, self.width, 4, dtype=torch.float32, device=gathered.device)
+        if gathered.is_cuda:
+            # the library's de-interleave kernel (shray_assemble_tiles_device), on the current stream
+            assert gathered.stride(2) == 1 and gathered.stride(1) == self.pixels * c
+            N.check(N.load_hip().shray_assemble_tiles_device(
+                C.c_void_p(gathered.data_ptr()), self.world, count, c, gathered.stride(0) * 4, gathered.stride(1) * 4,
+                self.width, self.height, self.tile_w, self.tile_h, C.c_void_p(self.output.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(gathered.device).cuda_stream)))
+            return self.output[0] if self.frames == 1 else self.output[:count]
+        # host tensors (the gloo rehearsal): the same mapping as one permute + crop
+        tiles_x = (self.width + self.tile_w - 1) // self.tile_w
+        tiles_y = (self.height + self.tile_h - 1) // self.tile_h
+        # tile t of frame f lives at gathered[t % world, f, t // world]
+        by_tile = gathered.reshape(self.world, count, self.per_rank, self.tile_h, self.tile_w, c).permute(1, 2, 0, 3, 4, 5)
+        by_tile = by_tile.reshape(count, self.per_rank * self.world, self.tile_h, self.tile_w, c)[:, : tiles_x * tiles_y]
+        grid = by_tile.reshape(count, tiles_y, tiles_x, self.tile_h, self.tile_w, c).permute(0, 1, 3, 2, 4, 5)
+        image = grid.reshape(count, tiles_y * self.tile_h, tiles_x * self.tile_w, c)[:, : self.height, : self.width]
+        self.output[:count, :, :, :c].copy_(image)
+        return self.output[0] if self.frames == 1 else self.output[:count]
 
 
 def render_frame_distributed(render_tiles, width: int, height: int, tile_w: int = DEFAULT_TILE,
                              tile_h: int = DEFAULT_TILE, group=None, device=None):
     """One-shot convenience wrapper around DistributedFrame."""
-    return DistributedFrame(width, height, tile_w, tile_h, group, device).render(render_tiles)
+    return DistributedFrame(width, height, tile_w, tile_h, group, device, rgb_wire=False).render(render_tiles)

@@ -72,6 +72,17 @@ class Scene:
             self._handle, C.byref(params), width, height, spp,
             C.byref(tiles) if tiles is not None else None, C.c_void_p(out_ptr), C.c_void_p(stream_ptr)))
 
+    def render_batch_into(self, params_list, width: int, height: int, spp: int, out_ptr: int, frame_stride_bytes: int,
+                          stream_ptr: int = 0, tiles: N.TileSet | None = None):
+        """`len(params_list)` frames in one launch; frame k goes to out_ptr + k * frame_stride_bytes
+        (shray_render_batch_device)."""
+        count = len(params_list)
+        array = (N.FrameParams * count)(*params_list)
+        N.check(self._lib.shray_render_batch_device(
+            self._handle, array, count, width, height, spp,
+            C.byref(tiles) if tiles is not None else None, C.c_void_p(out_ptr), frame_stride_bytes,
+            C.c_void_p(stream_ptr)))
+
 
 def tile_buffer_bytes(width: int, height: int, tiles: N.TileSet | None) -> int:
     return int(N.load_hip().shray_tile_buffer_bytes(width, height, C.byref(tiles) if tiles is not None else None))

@@ -219,6 +219,102 @@ def test_million_triangle_scene(pkg, gpu, oracle_mod, env_sky):
     scene.close()
 
 
+@pytest.mark.parametrize("channels", [3, 4])
+def test_deinterleave_kernel_matches_the_host_mapping(pkg, gpu, channels):
+    """shray_assemble_tiles_device (rank 0's de-interleave) against the numpy statement of the tile mapping."""
+    import ctypes as C
+    import torch
+    from shader_ray_amd import multigpu
+    N = pkg._native
+    rng = np.random.default_rng(11)
+    for (w, h, tw, th, world, frames) in ((100, 70, 16, 32, 3, 2), (200, 136, 32, 32, 8, 3), (33, 17, 16, 16, 1, 1), (64, 64, 32, 32, 5, 1)):
+        per = multigpu.max_tiles_per_rank(w, h, tw, th, world)
+        pad = 5                                            # frames need not be densely packed
+        gathered = rng.random((world, frames, per * th * tw * channels + pad), dtype=np.float32)
+        dev = torch.from_numpy(gathered).cuda()
+        out = torch.full((frames, h, w, 4), -3.0, dtype=torch.float32, device="cuda:0")
+        N.check(N.load_hip().shray_assemble_tiles_device(
+            C.c_void_p(dev.data_ptr()), world, frames, channels, dev.stride(0) * 4, dev.stride(1) * 4, w, h, tw, th,
+            C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        for f in range(frames):
+            parts = []
+            for r in range(world):
+                px = gathered[r, f, : per * th * tw * channels].reshape(-1, channels)
+                rgba = np.ones((px.shape[0], 4), dtype=np.float32)
+                rgba[:, :channels] = px
+                parts.append(rgba.reshape(-1))
+            want = multigpu.assemble_tiles(parts, w, h, tw, th)
+            assert np.array_equal(out[f].cpu().numpy(), want), (w, h, tw, th, world, f)
+    with pytest.raises(N.ShrayError):      # two channels is not a wire format
+        N.check(N.load_hip().shray_assemble_tiles_device(C.c_void_p(dev.data_ptr()), 5, 1, 2, 64, 64, 64, 64, 32, 32,
+                                                         C.c_void_p(out.data_ptr()), None))
+    with pytest.raises(N.ShrayError):      # strides smaller than a rank's frame
+        N.check(N.load_hip().shray_assemble_tiles_device(C.c_void_p(dev.data_ptr()), 5, 1, 3, 64, 64, 64, 64, 32, 32,
+                                                         C.c_void_p(out.data_ptr()), None))
+
+
+def test_frame_batches_equal_single_launches(pkg, gpu, bunny):
+    """shray_render_batch_device: every frame of a batch has its own parameters and lands where a
+    single launch would have put it; bytes between frames are left alone."""
+    import torch
+    world, desc, scene = bunny
+    N = pkg._native
+    W, H = 200, 136
+    frames = []
+    for k, (material, rot) in enumerate(((0, 0.0), (6, 0.9), (3, 2.1), (0, 4.0), (5, 5.5))):
+        view = world.default_view()
+        if rot:
+            view.object_rotation[:] = [rot, 0.26726124, 0.53452248, 0.80178373]
+        frames.append(world.frame_params(W, H, view, material=material))
+    frames[3].which = 5     # a non-differential debug view may share a batch with normal frames
+    stream = torch.cuda.current_stream().cuda_stream
+    for kernel in KERNELS:  # kernels 1 and 2 take the batch as consecutive launches
+        scene.set_kernel(kernel)
+        for tiles in (None, N.TileSet(32, 32, 3, 1), N.TileSet(16, 48, 2, 0)):
+            nbytes = pkg.tracer.tile_buffer_bytes(W, H, tiles)
+            stride = nbytes + 64
+            want = []
+            for p in frames:
+                one = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda:0")
+                scene.render_into(p, W, H, 1, one.data_ptr(), stream, tiles)
+                want.append(one)
+            got = torch.full((len(frames), stride // 4), -7.0, dtype=torch.float32, device="cuda:0")
+            scene.render_batch_into(frames, W, H, 1, got.data_ptr(), stride, stream, tiles)
+            torch.cuda.synchronize()
+            for k in range(len(frames)):
+                assert torch.equal(got[k, : nbytes // 4], want[k]), (kernel, tiles and tiles.tile_w, k)
+                assert bool((got[k, nbytes // 4:] == -7.0).all())
+            assert not torch.equal(want[0], want[1])
+    scene.set_kernel(0)
+    # more batches in flight than the library has parameter slots
+    nbytes = pkg.tracer.tile_buffer_bytes(W, H, None)
+    ring = torch.zeros(12, 2, nbytes // 4, dtype=torch.float32, device="cuda:0")
+    for j in range(12):
+        scene.render_batch_into([frames[j % 3], frames[(j + 1) % 3]], W, H, 1, ring[j].data_ptr(), nbytes, stream, None)
+    torch.cuda.synchronize()
+    singles = [scene.render(frames[k], W, H, 1) for k in range(3)]
+    for j in range(12):
+        assert np.array_equal(ring[j, 0].cpu().numpy().reshape(H, W, 4), singles[j % 3])
+        assert np.array_equal(ring[j, 1].cpu().numpy().reshape(H, W, 4), singles[(j + 1) % 3])
+
+    one = torch.empty(nbytes // 4 * 2, dtype=torch.float32, device="cuda:0")
+    with pytest.raises(N.ShrayError):
+        scene.render_batch_into([], W, H, 1, one.data_ptr(), nbytes, stream, None)
+    with pytest.raises(N.ShrayError):
+        scene.render_batch_into([frames[0]] * 65, W, H, 1, one.data_ptr(), nbytes, stream, None)
+    with pytest.raises(N.ShrayError):
+        scene.render_batch_into([frames[0]] * 2, W, H, 1, one.data_ptr(), nbytes - 16, stream, None)
+    mixed = frames[0].copy()
+    mixed.which = 1         # carries ray differentials: a different kernel instance
+    with pytest.raises(N.ShrayError) as e:
+        scene.render_batch_into([frames[0], mixed], W, H, 1, one.data_ptr(), nbytes, stream, None)
+    assert "differential" in str(e.value)
+    scene.render_batch_into([mixed, mixed], W, H, 1, one.data_ptr(), nbytes, stream, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(one[: nbytes // 4].cpu().numpy().reshape(H, W, 4), scene.render(mixed, W, H, 1))
+
+
 def test_error_paths(pkg, gpu, bunny, env_sky):
     N = pkg._native
     world, desc, scene = bunny

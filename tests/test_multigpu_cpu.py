@@ -25,7 +25,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, out_path):
+def worker(rank, world, port, out_path, frames, rgb_wire):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,34 +38,51 @@ def worker(rank, world, port, out_path):
     scene_world = pkg.World(helpers.small_trisrc())
     desc = scene_world.flatten()
     env = pkg.scenes.environment_hdr_sky(64)
-    params = scene_world.frame_params(W, H, material=6)
+    # every frame of a step has its own parameters (here: its own material)
+    params = [scene_world.frame_params(W, H, material=(6, 0, 3)[k % 3]) for k in range(frames)]
+    wanted = [oracle.render(desc, env, p, W, H, 1, threads=2)[0] for p in params]
 
     def render_tiles(tile_set, out):
-        # stand-in for Scene.render_into: fill this rank's packed tile buffer from the oracle
-        full, _ = oracle.render(desc, env, params, W, H, 1, threads=2)
+        # stand-in for Scene.render_batch_into: fill this rank's packed tiles of out.shape[0] frames from the oracle
         tiles, tiles_x, _ = multigpu.owned_tiles(W, H, tile_set.tile_w, tile_set.tile_h, tile_set.tile_stride, tile_set.tile_phase)
-        packed = out.view(-1, tile_set.tile_h, tile_set.tile_w, 4)
-        for k, t in enumerate(tiles):
-            x0, y0 = (t % tiles_x) * tile_set.tile_w, (t // tiles_x) * tile_set.tile_h
-            w, h = min(tile_set.tile_w, W - x0), min(tile_set.tile_h, H - y0)
-            packed[k, :h, :w] = torch.from_numpy(full[y0:y0 + h, x0:x0 + w])
+        for f in range(out.shape[0]):
+            packed = out[f].view(-1, tile_set.tile_h, tile_set.tile_w, 4)
+            packed.zero_()                                       # the kernel writes (0, 0, 0, 0) outside the frame
+            for k, t in enumerate(tiles):
+                x0, y0 = (t % tiles_x) * tile_set.tile_w, (t // tiles_x) * tile_set.tile_h
+                w, h = min(tile_set.tile_w, W - x0), min(tile_set.tile_h, H - y0)
+                packed[k, :h, :w] = torch.from_numpy(wanted[f][y0:y0 + h, x0:x0 + w])
 
-    frame = multigpu.render_frame_distributed(render_tiles, W, H, TILE, TILE, device="cpu")
-    if rank == 0:
-        want, _ = oracle.render(desc, env, params, W, H, 1, threads=2)
-        np.save(out_path, np.stack([frame.numpy(), want]))
+    if frames == 1 and not rgb_wire:
+        got = [multigpu.render_frame_distributed(render_tiles, W, H, TILE, TILE, device="cpu")]
+        short = None
     else:
-        assert frame is None
+        split = multigpu.DistributedFrame(W, H, TILE, TILE, device="cpu", frames=frames, rgb_wire=rgb_wire)
+        out = split.render(render_tiles)
+        got = None if out is None else ([out.clone()] if frames == 1 else list(out.clone()))
+        # a shorter last step reuses the same buffers
+        short = split.render(render_tiles, count=max(1, frames - 1))
+        got = [None] if got is None else got
+    if rank == 0:
+        assert all(g is not None for g in got)
+        if short is not None:
+            short = short if short.dim() == 4 else short.unsqueeze(0)
+            assert short.shape[0] == max(1, frames - 1)
+            for f in range(short.shape[0]):
+                assert np.array_equal(short[f].numpy(), wanted[f])
+        np.save(out_path, np.stack([np.stack([g.numpy() for g in got]), np.stack(wanted)]))
+    else:
+        assert got == [None]
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_tiles_gather_and_reassemble(world, tmp_path, pkg, oracle_mod):
+@pytest.mark.parametrize("world,frames,rgb_wire", [(2, 1, False), (3, 1, False), (2, 3, True), (3, 2, True), (2, 1, True)])
+def test_tiles_gather_and_reassemble(world, frames, rgb_wire, tmp_path, pkg, oracle_mod):
     out = str(tmp_path / "frames.npy")
-    mp.spawn(worker, args=(world, free_port(), out), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), out, frames, rgb_wire), nprocs=world, join=True)
     got, want = np.load(out)
-    assert got.shape == (H, W, 4)
+    assert got.shape == (frames, H, W, 4)
     assert np.array_equal(got, want)
 
 

@@ -3,5 +3,5 @@
 CFG=${1:-4}; SPP=${2:-1}
 echo "== shipped"; python3 profiles/config_probe.py $CFG $SPP || exit 1
 for lib in shader-ray_amd/_variants/*.so; do
-  echo "== $(basename $lib)"; KERNELS=0 SHRAY_HIP_LIB=$PWD/$lib python3 profiles/config_probe.py $CFG $SPP | grep kernel || exit 1
+  echo "== $(basename $lib)"; KERNELS=${KERNELS:-0} SHRAY_HIP_LIB=$PWD/$lib python3 profiles/config_probe.py $CFG $SPP | grep kernel || exit 1
 done

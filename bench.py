@@ -10,6 +10,12 @@ renders its interleaved tiles with the HIP kernel and (N > 1) the packed tile bu
 gathered to rank 0 over RCCL and de-interleaved.  Scene and environment are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
+Successive frames are independent.  N = 1: two frames in flight on two HIP streams.  N > 1: a
+launch carries N consecutive frames (the rank's tiles of each; shray_render_batch_device), one
+gather moves all N, and two such launches alternate on two streams -- a rank's share of ONE
+frame is latency-bound, see DESIGN.md section 6.  Exactly K frames are rendered in the timed
+region either way (the last launch is shorter when N does not divide K).
+
 For N > 1 launch as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W

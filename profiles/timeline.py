@@ -28,7 +28,7 @@ def main():
     import helpers
     pkg = load_package()
     N = pkg._native
-    N.HIP_LIB = os.path.join(N.PKG_DIR, "libshray_hip_diag.so")
+    N.HIP_LIB = os.environ.get("SHRAY_DIAG_LIB") or os.path.join(N.PKG_DIR, "libshray_hip_diag.so")
     lib = N.load_hip()
     lib.shray_debug_timeline.restype = C.c_int
     world = pkg.World(helpers.bunny_trisrc())

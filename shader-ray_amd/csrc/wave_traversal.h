@@ -32,6 +32,11 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 
 // Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
 // cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
+// leaf_stage tests two triangles of a leaf per turn (1) or one (0)
+#ifndef SHRAY_LEAF_PAIRS
+#define SHRAY_LEAF_PAIRS 1
+#endif
+
 #ifdef SHRAY_DIAGNOSTICS
 #define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SHRAY_DIAG_T0 const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
@@ -198,6 +203,34 @@ __device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint
     t.hit.bv = w;
 }
 
+// triangle_intersect without the store and without the `d > hit.t` early-out: the candidate
+// (dist, u, w) of triangle data q0..q2 against the lane's ray; returns whether it passes every
+// other early-out of fs:312-340 (the predicate is a conjunction, so their order does not matter;
+// NaN operands fail the same comparisons as upstream).  Two of these are independent instruction
+// chains, which is what a wave running alone on its SIMD needs (leaf_stage).
+__device__ __forceinline__ bool lane_triangle_candidate(const LaneTraversal &t, const float4 q0, const float4 q1,
+                                                        const float4 q2, float &dist, float &u, float &w)
+{
+    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
+    const V3 M = cross3(e1, t.D);
+    const float det = dot3(e0, M);
+    const float inv_det = 1.0f / det;
+    const V3 T = t.P - v0;
+    const V3 Q = cross3(T, e0);
+    dist = -dot3(e1, Q) * inv_det;
+    u = dot3(T, M) * inv_det;
+    w = dot3(t.D, Q) * inv_det;
+    if (det > -0.0000001f && det < 0.0000001f)
+        return false;
+    if (dist < t.leaf_r0 || dist > t.leaf_r1)
+        return false;
+    if (u < 0.0f || u > 1.0f)
+        return false;
+    if (w < 0.0f || u + w > 1.0f)
+        return false;
+    return true;
+}
+
 // The three 16-byte words of a packed triangle, fetched as three dwordx4 loads issued back to
 // back.  (Left to itself the compiler splits them into partial loads and sinks some behind the
 // `det` early-out of the test, which costs a second dependent memory round trip per triangle.)
@@ -250,6 +283,42 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
 {
     if (!wave_ballot(state == LT_LEAF))
         return;
+#if SHRAY_LEAF_PAIRS
+    // two triangles per turn: both loads issued together, the two tests are independent chains;
+    // the second is applied after the first, against the hit.t the first may have set (fs:416-424 order)
+    for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j += 2) {
+        SHRAY_DIAG_COUNT(1);
+        if (state == LT_LEAF && j < t.leaf_count) {
+            const bool second = j + 1 < t.leaf_count;
+            const float4 *tri = reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * (t.leaf_first + j);
+            float4 a0, a1, a2, b0, b1, b2;
+            SHRAY_DIAG_T0
+            load_packed_triangle(tri, a0, a1, a2);
+            load_packed_triangle(tri + (second ? 3 : 0), b0, b1, b2);
+            SHRAY_DIAG_WAIT(5);
+            if (COUNT)
+                rc.triangle_tests += second ? 2 : 1;
+            float da, ua, wa, db, ub, wb;
+            const bool pass_a = lane_triangle_candidate(t, a0, a1, a2, da, ua, wa);
+            const bool pass_b = lane_triangle_candidate(t, b0, b1, b2, db, ub, wb) && second;
+            if (pass_a && !(da > t.hit.t)) {
+                t.hit.which = (float)(t.leaf_first + j);
+                t.hit.t = da;
+                t.hit.bu = ua;
+                t.hit.bv = wa;
+            }
+            if (pass_b && !(db > t.hit.t)) {   // against the hit.t the first triangle may just have set
+                t.hit.which = (float)(t.leaf_first + j + 1);
+                t.hit.t = db;
+                t.hit.bu = ub;
+                t.hit.bv = wb;
+            }
+        }
+    }
+    if (state == LT_LEAF)
+        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+    return;
+#endif
     for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
         SHRAY_DIAG_COUNT(1);
         if (state == LT_LEAF && j < t.leaf_count) {

@@ -37,6 +37,11 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 #define SHRAY_LEAF_PAIRS 1
 #endif
 
+// node visits per lane between two evaluations of inner_stage's exit tests
+#ifndef SHRAY_NODE_TURNS
+#define SHRAY_NODE_TURNS 2
+#endif
+
 #ifdef SHRAY_DIAGNOSTICS
 #define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SHRAY_DIAG_T0 const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
@@ -261,14 +266,17 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
     for (;;) {
         if (!wave_ballot(state == LT_WALK))
             return;
-        SHRAY_DIAG_COUNT(0);
-        if (state == LT_WALK) {
-            const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-            SHRAY_DIAG_T0
-            const float4 lo = nodes[2u * t.node];
-            const float4 hi = nodes[2u * t.node + 1u];
-            SHRAY_DIAG_WAIT(4);
-            state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+#pragma unroll
+        for (int turn = 0; turn < SHRAY_NODE_TURNS; turn++) {   // the exit tests below run once per SHRAY_NODE_TURNS visits
+            SHRAY_DIAG_COUNT(0);
+            if (state == LT_WALK) {
+                const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
+                SHRAY_DIAG_T0
+                const float4 lo = nodes[2u * t.node];
+                const float4 hi = nodes[2u * t.node + 1u];
+                SHRAY_DIAG_WAIT(4);
+                state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+            }
         }
         const int walking = __popcll(wave_ballot(state == LT_WALK));
         if (walking < keep_walking && (wave_ballot(state == LT_LEAF) || others_waiting))

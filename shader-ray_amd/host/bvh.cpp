@@ -17,16 +17,41 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <map>
 
 namespace {
 
 bvh_build_options g_options;
 bool g_options_from_env = false;
-bvh_build_stats g_stats;
-std::map<int, int> g_nodes_per_level;
-std::map<int, int> g_leaves_per_size;
-int g_shapes_done = 0;
+// Everything the build counts.  A sub-tree built on another thread counts into its own tally,
+// added to the parent's when the thread is joined.
+struct build_tally {
+    bvh_build_stats stats;
+    std::map<int, int> nodes_per_level;
+    std::map<int, int> leaves_per_size;
+    int shapes_done = 0;
+
+    void add(const build_tally &other)
+    {
+        stats.node_count += other.stats.node_count;
+        stats.leaf_count += other.stats.leaf_count;
+        stats.max_level = std::max(stats.max_level, other.stats.max_level);
+        stats.large_leaves += other.stats.large_leaves;
+        for (const auto &kv : other.nodes_per_level)
+            nodes_per_level[kv.first] += kv.second;
+        for (const auto &kv : other.leaves_per_size)
+            leaves_per_size[kv.first] += kv.second;
+        shapes_done += other.shapes_done;
+    }
+};
+build_tally g_tally;
+
+// Sub-trees over disjoint triangle ranges are independent (the partition works in place inside its
+// own range), so the two children of a large node are built concurrently; the tree, the boxes and
+// the triangle order are those of the serial build.  SHRAY_BVH_THREADS=0 builds serially.
+const unsigned int kParallelMinTriangles = 32768;
+bool g_parallel_build = true;
 
 const int kMaxBins = 40;
 const int kLeafSizeStatsCap = 64;
@@ -40,6 +65,7 @@ void read_env_once()
     if (const char *s = getenv("BVH_LEAF_MAX")) g_options.leaf_max = atoi(s);
     if (const char *s = getenv("SAH_CTRAV")) g_options.sah_ctrav = atof(s);
     if (const char *s = getenv("SAH_CISEC")) g_options.sah_cisec = atof(s);
+    if (const char *s = getenv("SHRAY_BVH_THREADS")) g_parallel_build = atoi(s) != 0;
 }
 
 inline float half_area_x2(const vec3 &d) { return 2 * (d.x * d.y + d.x * d.z + d.y * d.z); }
@@ -62,14 +88,14 @@ inline int truncate_like_x86(float f)
     return (int)f;
 }
 
-group *emit_leaf(triangle_set_ptr mesh, int start, int count, int level)
+group *emit_leaf(const triangle_set_ptr &mesh, int start, int count, int level, build_tally &tally)
 {
-    g_shapes_done += count;
-    g_stats.node_count++;
-    g_stats.leaf_count++;
-    g_stats.max_level = std::max(g_stats.max_level, level);
-    g_nodes_per_level[level]++;
-    g_leaves_per_size[std::min(count, kLeafSizeStatsCap)]++;
+    tally.shapes_done += count;
+    tally.stats.node_count++;
+    tally.stats.leaf_count++;
+    tally.stats.max_level = std::max(tally.stats.max_level, level);
+    tally.nodes_per_level[level]++;
+    tally.leaves_per_size[std::min(count, kLeafSizeStatsCap)]++;
     return new group(mesh, start, (unsigned int)count);
 }
 
@@ -156,32 +182,27 @@ bvh_build_options &bvh_options()
     return g_options;
 }
 
-const bvh_build_stats &bvh_stats() { return g_stats; }
+const bvh_build_stats &bvh_stats() { return g_tally.stats; }
 
-void reset_bvh_stats()
-{
-    g_stats = bvh_build_stats();
-    g_nodes_per_level.clear();
-    g_leaves_per_size.clear();
-    g_shapes_done = 0;
-}
+void reset_bvh_stats() { g_tally = build_tally(); }
 
 void print_bvh_stats()
 {
-    fprintf(stderr, "bvh: %d nodes, %d leaves, deepest level %d\n", g_stats.node_count, g_stats.leaf_count,
-            g_stats.max_level);
-    for (const auto &kv : g_nodes_per_level)
+    fprintf(stderr, "bvh: %d nodes, %d leaves, deepest level %d\n", g_tally.stats.node_count, g_tally.stats.leaf_count,
+            g_tally.stats.max_level);
+    for (const auto &kv : g_tally.nodes_per_level)
         fprintf(stderr, "  level %2d: %7d nodes\n", kv.first, kv.second);
-    for (const auto &kv : g_leaves_per_size)
+    for (const auto &kv : g_tally.leaves_per_size)
         fprintf(stderr, "  %s%2d triangles: %7d leaves\n", kv.first == kLeafSizeStatsCap ? ">=" : "  ", kv.first,
                 kv.second);
 }
 
-group *make_bvh(triangle_set_ptr mesh, int start, unsigned int count, int level)
+namespace {
+
+group *build_subtree(const triangle_set_ptr &mesh, int start, unsigned int count, int level, build_tally &tally)
 {
-    read_env_once();
     if (level >= g_options.max_depth || count <= g_options.leaf_max)
-        return emit_leaf(mesh, start, (int)count, level);
+        return emit_leaf(mesh, start, (int)count, level, tally);
 
     std::vector<indexed_triangle> &tris = mesh->triangles;
 
@@ -199,8 +220,8 @@ group *make_bvh(triangle_set_ptr mesh, int start, unsigned int count, int level)
     if (best >= unsplit) {
         if (g_options.verbose)
             host_info("bvh: no split beats a %u-triangle leaf at level %d\n", count, level);
-        g_stats.large_leaves++;
-        return emit_leaf(mesh, start, (int)count, level);
+        tally.stats.large_leaves++;
+        return emit_leaf(mesh, start, (int)count, level, tally);
     }
 
     const int mid = split_in_place(tris, start, (int)count, axis, plane);
@@ -209,17 +230,36 @@ group *make_bvh(triangle_set_ptr mesh, int start, unsigned int count, int level)
     if (below <= 0 || above <= 0) {
         if (g_options.verbose)
             host_info("bvh: split left one side empty, %u-triangle leaf at level %d\n", count, level);
-        g_stats.large_leaves++;
-        return emit_leaf(mesh, start, (int)count, level);
+        tally.stats.large_leaves++;
+        return emit_leaf(mesh, start, (int)count, level, tally);
     }
 
     vec3 direction(0.0f);
     (axis == 0 ? direction.x : (axis == 1 ? direction.y : direction.z)) = 1.0f;
 
-    group *neg = make_bvh(mesh, start, (unsigned int)below, level + 1);
-    group *pos = make_bvh(mesh, mid, (unsigned int)above, level + 1);
-    g_stats.node_count++;
-    g_stats.max_level = std::max(g_stats.max_level, level);
-    g_nodes_per_level[level]++;
+    group *neg, *pos;
+    if (g_parallel_build && count >= kParallelMinTriangles) {
+        build_tally other;
+        std::future<group *> negative = std::async(std::launch::async, [&] {
+            return build_subtree(mesh, start, (unsigned int)below, level + 1, other);
+        });
+        pos = build_subtree(mesh, mid, (unsigned int)above, level + 1, tally);
+        neg = negative.get();
+        tally.add(other);
+    } else {
+        neg = build_subtree(mesh, start, (unsigned int)below, level + 1, tally);
+        pos = build_subtree(mesh, mid, (unsigned int)above, level + 1, tally);
+    }
+    tally.stats.node_count++;
+    tally.stats.max_level = std::max(tally.stats.max_level, level);
+    tally.nodes_per_level[level]++;
     return new group(mesh, neg, pos, direction, vertex_box);
+}
+
+}   // namespace
+
+group *make_bvh(triangle_set_ptr mesh, int start, unsigned int count, int level)
+{
+    read_env_once();
+    return build_subtree(mesh, start, count, level, g_tally);
 }

@@ -1,8 +1,14 @@
 """Loader behaviour and error handling of the host layer, mirroring what the reference's
 loaders do with the same input (trisrc-support.cpp:43-105, obj-support.cpp:226-360,
 world.cpp:46-134)."""
+import os
+
 import numpy as np
 import pytest
+
+import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def write(path, text):
@@ -139,3 +145,32 @@ def test_trackball_rotation_matches_the_reference_formulas(pkg):
     assert np.allclose(m[:3, :3], rot, atol=1e-6)
     # the object matrix maps world to object space about the scene centre (ray.cpp:118-123)
     assert np.allclose(np.array(fp.object_normal_inverse[:]).reshape(4, 4).T[:3, :3], rot.T, atol=1e-6)
+
+
+def test_threaded_bvh_build_equals_the_serial_build(pkg):
+    """Large nodes build their two sub-trees concurrently (host/bvh.cpp); the flattened arrays --
+    tree, boxes, triangle order -- must be those of the serial build (SHRAY_BVH_THREADS=0)."""
+    import hashlib
+    import subprocess
+    import sys
+
+    def digest(arrays):
+        h = hashlib.sha256()
+        for key in sorted(arrays):
+            v = arrays[key]
+            h.update(key.encode())
+            h.update(v.tobytes() if isinstance(v, np.ndarray) else str(v).encode())
+        return h.hexdigest()
+
+    path = helpers.bunny_trisrc()           # 69,168 triangles: the root and both its children fork
+    threaded = digest(pkg.World(path).arrays())
+    code = ("import sys, hashlib, numpy as np; sys.path[:0] = [%r, %r]\n"
+            "from __graft_entry__ import load_package\n"
+            "a = load_package().World(%r).arrays()\n"
+            "h = hashlib.sha256()\n"
+            "for k in sorted(a):\n"
+            "    v = a[k]; h.update(k.encode()); h.update(v.tobytes() if isinstance(v, np.ndarray) else str(v).encode())\n"
+            "print(h.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"), path)
+    env = dict(os.environ, SHRAY_BVH_THREADS="0")
+    serial = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()[-1]
+    assert threaded == serial

@@ -18,6 +18,8 @@
 
 #include <cerrno>
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -252,8 +254,19 @@ void get_shader_data(world_ptr w, scene_shader_data &data, unsigned int width)
         }
     });
 
+    // the eight direction tables are independent walks (each writes only its own code's links and table): one thread each
+    bool complete[kDirectionCodes];
+    {
+        std::vector<std::thread> walkers;
+        for (int code = 0; code < kDirectionCodes; code++)
+            walkers.emplace_back([&, code] {
+                complete[code] = thread_direction(w->root, code, data.group_hitmiss + 2 * node_texels * code);
+            });
+        for (std::thread &t : walkers)
+            t.join();
+    }
     for (int code = 0; code < kDirectionCodes; code++) {
-        if (!thread_direction(w->root, code, data.group_hitmiss + 2 * node_texels * code))
+        if (!complete[code])
             fprintf(stderr, "hitmiss: tree deeper than %d, direction table %d is incomplete\n", kLinkStackCapacity, code);
     }
     host_info("hitmiss: %f seconds\n", seconds_since(then));

@@ -26,11 +26,20 @@ namespace shray {
 #ifndef SHRAY_UNIFIED_WALK
 #define SHRAY_UNIFIED_WALK 0
 #endif
-// lanes still walking below which the node loop yields to the leaf stage (when lanes are parked)
+// The node loop yields to the leaf stage (when lanes are parked) once fewer than a threshold of lanes
+// are still walking.  SHRAY_RELATIVE_KEEP: the threshold is SHRAY_KEEP_WALKING / 64 of the lanes still
+// in this traversal (at least SHRAY_KEEP_FLOOR) -- a wave with eight live lanes should not leave the node
+// loop after every visit; otherwise it is SHRAY_KEEP_WALKING lanes.  Swept in profiles/variant_sweep.sh.
 #ifndef SHRAY_KEEP_WALKING
-#define SHRAY_KEEP_WALKING 12
+#define SHRAY_KEEP_WALKING 28
 #endif
 constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
+#ifndef SHRAY_RELATIVE_KEEP
+#define SHRAY_RELATIVE_KEEP 1
+#endif
+#ifndef SHRAY_KEEP_FLOOR
+#define SHRAY_KEEP_FLOOR 2
+#endif
 // parked lanes required before walk_stage spends instructions on a triangle step while others walk
 #ifndef SHRAY_MIN_PARKED
 #define SHRAY_MIN_PARKED 1
@@ -64,7 +73,14 @@ struct StackTraversal {
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
+#if SHRAY_RELATIVE_KEEP
+            // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
+            const int alive = __popcll(wave_ballot(state != LT_ENDED));
+            const int keep = max(SHRAY_KEEP_FLOOR, (alive * kStackKeepWalking + 32) >> 6);
+            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
+#else
             inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
+#endif
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif

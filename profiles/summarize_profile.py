@@ -12,7 +12,14 @@ root = sys.argv[1]
 
 
 def rows(pattern):
+    # gpurun merges every call's files into the same local tree: per directory keep only the newest run
+    # (rocprofv3 prefixes its files with the process id)
+    newest = {}
     for path in glob.glob(os.path.join(root, pattern), recursive=True):
+        d = os.path.dirname(path)
+        if d not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d]):
+            newest[d] = path
+    for path in sorted(newest.values()):
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
                 yield r

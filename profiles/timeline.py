@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--material", type=int, default=0)
+    ap.add_argument("--million", action="store_true", help="the 1M-triangle scene instead of the bunny-class mesh")
     args = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime)
     from __graft_entry__ import load_package
@@ -31,7 +32,7 @@ def main():
     N.HIP_LIB = os.environ.get("SHRAY_DIAG_LIB") or os.path.join(N.PKG_DIR, "libshray_hip_diag.so")
     lib = N.load_hip()
     lib.shray_debug_timeline.restype = C.c_int
-    world = pkg.World(helpers.bunny_trisrc())
+    world = pkg.World(helpers.million_obj() if args.million else helpers.bunny_trisrc())
     desc = world.flatten()
     scene = pkg.Scene(desc, pkg.scenes.environment_hdr_sky(2048), device=0)
     scene.set_kernel(args.kernel)
@@ -92,6 +93,11 @@ def main():
         print(f"heavy wave: block ({blk % px},{blk // px}) wave {i % 4} dur {dur[i]:.1f} us start +{(t0[i] - start) * 10e-3:.1f} us; "
               f"node loop {ni} iterations x {nc / max(ni, 1):.0f} cycles, leaf loop {li} iterations x {lc / max(li, 1):.0f} cycles, "
               f"in loops {(nc + lc) / 2.4e3:.0f} us at 2.4 GHz; load wait per iteration: node {int(stamps[i, 8]) / max(ni, 1):.0f}, triangle {int(stamps[i, 9]) / max(li, 1):.0f} cycles")
+    for i in order[:5]:
+        print(f"  wave {i}: {int(stamps[i, 10])} leaf stages, {int(stamps[i, 5])} leaf-loop turns now, "
+              f"{int(stamps[i, 11])} 64-wide rounds if triangles of all parked lanes were dealt across the wave")
+    st = stamps[:, 10:12].astype(np.float64).sum(axis=0)
+    print(f"all waves: {st[0]:.3g} leaf stages, {stamps[:, 5].astype(np.float64).sum():.3g} leaf-loop turns, {st[1]:.3g} 64-wide rounds")
     tot = stamps[:, 4:8].astype(np.float64).sum(axis=0)
     print(f"all waves: node loop {tot[0]:.3g} iterations x {tot[2] / tot[0]:.0f} cycles; leaf loop {tot[1]:.3g} iterations x {tot[3] / max(tot[1], 1):.0f} cycles")
     w = stamps[:, 8:10].astype(np.float64).sum(axis=0)

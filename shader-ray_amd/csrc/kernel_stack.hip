@@ -14,9 +14,13 @@ constexpr int kBlock = 256;
 bool g_diag_plain_kernel = false;
 #endif
 
-// tuning hooks (experiments: make HIP_EXTRA='-DSHRAY_MIN_WAVES=5 -DSHRAY_LDS_PAD=32768')
+// Waves per SIMD the register allocator must leave room for.  The plain kernel sits at the 128-register
+// boundary (arch VGPRs + the AGPRs that hold spilled SGPRs): a few registers more and only three
+// waves fit.  Asking for five (<= 102 registers) costs some extra spill traffic and wins it back with
+// occupancy: 0.593 -> 0.571 ms on the 1080p frame, 2.04 -> 1.88 ms on the 1M-triangle scene
+// (4: 0.598 / 2.10, 6: 0.593 / 1.79; profiles/variant_sweep.sh).
 #ifndef SHRAY_MIN_WAVES
-#define SHRAY_MIN_WAVES 1
+#define SHRAY_MIN_WAVES 5
 #endif
 #ifndef SHRAY_LDS_PAD
 #define SHRAY_LDS_PAD 0

@@ -75,7 +75,8 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __bui
 
 // group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
 template <bool COUNT>
-__device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t, V3 P, V3 D, RayCounters &rc)
+__device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t, V3 P, V3 D, RayCounters &rc,
+                                           bool counted = true)
 {
     t.P = P;
     t.D = D;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t
     t.node = sc.packed_root;
     t.sp = 0;
     t.iter = 0;
-    if (COUNT)
+    if (COUNT && counted)
         rc.traversals++;
 }
 
@@ -291,6 +292,15 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
 {
     if (!wave_ballot(state == LT_LEAF))
         return;
+#ifdef SHRAY_DIAGNOSTICS
+    {   // how much a triangle-parallel leaf stage could save: stages, and 64-wide rounds over all parked triangles
+        unsigned int total = (state == LT_LEAF) ? t.leaf_count : 0u;
+        for (int off = 32; off > 0; off >>= 1)
+            total += __shfl_xor(total, off, 64);
+        diag_tally_ref[6] += 1;
+        diag_tally_ref[7] += (total + 63u) / 64u;
+    }
+#endif
 #if SHRAY_LEAF_PAIRS
     // two triangles per turn: both loads issued together, the two tests are independent chains;
     // the second is applied after the first, against the hit.t the first may have set (fs:416-424 order)

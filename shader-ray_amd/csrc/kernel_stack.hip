@@ -14,13 +14,14 @@ constexpr int kBlock = 256;
 bool g_diag_plain_kernel = false;
 #endif
 
-// Waves per SIMD the register allocator must leave room for.  The plain kernel sits at the 128-register
-// boundary (arch VGPRs + the AGPRs that hold spilled SGPRs): a few registers more and only three
-// waves fit.  Asking for five (<= 102 registers) costs some extra spill traffic and wins it back with
-// occupancy: 0.593 -> 0.571 ms on the 1080p frame, 2.04 -> 1.88 ms on the 1M-triangle scene
-// (4: 0.598 / 2.10, 6: 0.593 / 1.79; profiles/variant_sweep.sh).
+// Waves per SIMD the register allocator must leave room for.  Left alone, the plain kernel sits at the
+// 128-register boundary (arch VGPRs + the AGPRs that hold spilled SGPRs): a few registers more and only
+// three waves fit.  Asking for six (<= 85 registers) spills more to scratch and wins it back with
+// occupancy -- with the plain one-triangle / one-visit loops of wave_traversal.h, which need fewer
+// registers: one frame 0.58 -> 0.558 ms, pipelined 0.389 -> 0.357 ms, 1M-triangle scene 2.04 -> 1.77 ms.
+// Seven and eight lose again on the benchmark frame (profiles/ab_sweep.sh).
 #ifndef SHRAY_MIN_WAVES
-#define SHRAY_MIN_WAVES 5
+#define SHRAY_MIN_WAVES 6
 #endif
 #ifndef SHRAY_LDS_PAD
 #define SHRAY_LDS_PAD 0

@@ -32,14 +32,15 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 
 // Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
 // cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
-// leaf_stage tests two triangles of a leaf per turn (1) or one (0)
+// leaf_stage tests two triangles of a leaf per turn (1) or one (0).  Fewer instructions, more registers:
+// ahead at four waves per SIMD, behind at the six the stack kernel asks for (kernel_stack.hip)
 #ifndef SHRAY_LEAF_PAIRS
-#define SHRAY_LEAF_PAIRS 1
+#define SHRAY_LEAF_PAIRS 0
 #endif
 
-// node visits per lane between two evaluations of inner_stage's exit tests
+// node visits per lane between two evaluations of inner_stage's exit tests (same trade as above)
 #ifndef SHRAY_NODE_TURNS
-#define SHRAY_NODE_TURNS 2
+#define SHRAY_NODE_TURNS 1
 #endif
 
 #ifdef SHRAY_DIAGNOSTICS

@@ -701,7 +701,10 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     FrameView *d_views = (FrameView *)scene->batch_views.p + (size_t)slot * SHRAY_MAX_BATCH;
     memcpy(staged, views.data(), sizeof(FrameView) * (size_t)count);
     HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
-    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], (float4 *)d_rgba_out,
+    bool all_metal = true;
+    for (const FrameView &v : views)
+        all_metal = all_metal && !(v.diffuse_color[0] > 0.0f && v.diffuse_color[1] > 0.0f && v.diffuse_color[2] > 0.0f);
+    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], all_metal, (float4 *)d_rgba_out,
                                             (size_t)frame_stride_bytes / 16, stream, scene->stack_levels);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));

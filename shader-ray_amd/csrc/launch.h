@@ -20,7 +20,8 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 
 // `count` frames in one launch (grid.y = frame): d_frames[k] is frame k's view, written to
 // out + k * frame_stride (in float4 units); `first` is frame 0's view (grid shape, differential class)
-hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first,
+// all_metal: every frame's diffuse colour is zero (selects the kernel instance without the diffuse branch)
+hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
 
 // rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,

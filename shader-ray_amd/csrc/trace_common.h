@@ -285,7 +285,9 @@ __device__ __forceinline__ void environment_coords(V3 d, float &s, float &t)
 // trace(), fs:552-582, with intersect_and_shade (fs:484-522) and
 // approximate_diffuse (fs:447-472) inlined.  Traversal::closest() runs
 // group_intersect (fs:386-443) on an object-space ray.
-template <class Traversal, bool COUNT, bool DIFF>
+// METAL: the caller guarantees a zero diffuse colour (the shader's metals, ray.cpp:698-704), so the
+// diffuse / shadow-ray branch and the `accumulated` sum do not exist in this instance.
+template <class Traversal, bool COUNT, bool DIFF, bool METAL = false>
 __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr, Traversal &trav, V3 P, V3 D,
                                        RayCounters &rc, Differentials df = Differentials())
 {
@@ -294,7 +296,7 @@ __device__ __forceinline__ V3 trace_ray(const SceneView &sc, const FrameView &fr
     const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);
     const V3 spec = mk(fr.specular_color[0], fr.specular_color[1], fr.specular_color[2]);
     const V3 diff = mk(fr.diffuse_color[0], fr.diffuse_color[1], fr.diffuse_color[2]);
-    const bool has_diffuse = diff.x > 0.0f && diff.y > 0.0f && diff.z > 0.0f;   // fs:570 (object_color is white)
+    const bool has_diffuse = !METAL && diff.x > 0.0f && diff.y > 0.0f && diff.z > 0.0f;   // fs:570 (object_color is white)
 
     for (int bounce = 0; bounce < fr.bounce_count; bounce++) {
         Hit hit{kFar, -1.0f, 0.0f, 0.0f};
@@ -358,7 +360,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 
 // One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four
 // 8x8 wave tiles so that the 64 rays of a wave stay spatially coherent.
-template <class Traversal, bool COUNT, bool DIFF = false>
+// ONE_SAMPLE / METAL: instances for spp == 1 and for a zero diffuse colour (checked by the launcher):
+// no sample loop, no radiance sum, no diffuse branch -- fewer live registers across the traversal.
+template <class Traversal, bool COUNT, bool DIFF = false, bool ONE_SAMPLE = false, bool METAL = false>
 __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                              DeviceCounters *counters, Traversal &trav)
 {
@@ -420,7 +424,7 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
             for (int j = 0; j < 5; j++) {
                 const float du = ((float)i / 5.0f - .5f), dv = ((float)j / 5.0f - .5f);
                 const V3 D = unit(dir + right * (du * .2f) + up * (dv * .2f));
-                acc = acc + trace_ray<Traversal, COUNT, false>(sc, fr, trav, P, D, rc);
+                acc = acc + trace_ray<Traversal, COUNT, false, METAL>(sc, fr, trav, P, D, rc);
             }
         }
         result = acc / 25.0f;
@@ -429,7 +433,8 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
     } else if (inside) {
         const float fw = (float)fr.width, fh = (float)fr.height, fn = (float)fr.spp;
         V3 sum = mk(0, 0, 0);
-        for (int s = 0; s < fr.spp; s++) {
+        const int samples = ONE_SAMPLE ? 1 : fr.spp;
+        for (int s = 0; s < samples; s++) {
             // sub-pixel pattern of the oracle (oracle/shader_oracle.cpp header): centred Hammersley
             const float ox = ((float)s + 0.5f) / fn;
             const float oy = (float)__brev((unsigned int)s) * 2.3283064365386963e-10f + 0.5f / fn;
@@ -442,10 +447,10 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
             Differentials df;
             if (DIFF)
                 primary_differentials(fr, D, df);
-            const V3 radiance = trace_ray<Traversal, COUNT, DIFF>(sc, fr, trav, P, D, rc, df);
-            sum = (fr.spp == 1) ? radiance : sum + radiance;
+            const V3 radiance = trace_ray<Traversal, COUNT, DIFF, METAL>(sc, fr, trav, P, D, rc, df);
+            sum = (ONE_SAMPLE || fr.spp == 1) ? radiance : sum + radiance;
         }
-        result = (fr.spp == 1) ? sum : sum / fn;
+        result = (ONE_SAMPLE || fr.spp == 1) ? sum : sum / fn;
         if (fr.tonemap)
             result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
     }

@@ -40,7 +40,7 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 
 // node visits per lane between two evaluations of inner_stage's exit tests (same trade as above)
 #ifndef SHRAY_NODE_TURNS
-#define SHRAY_NODE_TURNS 1
+#define SHRAY_NODE_TURNS 2
 #endif
 
 #ifdef SHRAY_DIAGNOSTICS

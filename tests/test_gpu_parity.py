@@ -298,6 +298,19 @@ def test_frame_batches_equal_single_launches(pkg, gpu, bunny):
         assert np.array_equal(ring[j, 0].cpu().numpy().reshape(H, W, 4), singles[j % 3])
         assert np.array_equal(ring[j, 1].cpu().numpy().reshape(H, W, 4), singles[(j + 1) % 3])
 
+    # the kernel instances picked by the launcher: all frames metallic (no diffuse branch), spp == 1 or not
+    metals = []
+    for rot in (0.4, 1.7):
+        view = world.default_view()
+        view.object_rotation[:] = [rot, 0.26726124, 0.53452248, 0.80178373]
+        metals.append(world.frame_params(W, H, view, material=0))
+    for spp, batch in ((1, metals), (3, metals), (3, [frames[1], frames[0]])):
+        got = torch.zeros(2, nbytes // 4, dtype=torch.float32, device="cuda:0")
+        scene.render_batch_into(batch, W, H, spp, got.data_ptr(), nbytes, stream, None)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.array_equal(got[k].cpu().numpy().reshape(H, W, 4), scene.render(batch[k], W, H, spp)), (spp, k)
+
     one = torch.empty(nbytes // 4 * 2, dtype=torch.float32, device="cuda:0")
     with pytest.raises(N.ShrayError):
         scene.render_batch_into([], W, H, 1, one.data_ptr(), nbytes, stream, None)

@@ -10,7 +10,7 @@ import re
 import sys
 
 summary = open(sys.argv[1]).read()
-kernel = sys.argv[2] if len(sys.argv) > 2 else "trace_stack_kernel<false, false, true, true>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "trace_stack_batch_kernel<false, true, true>"
 block = summary[summary.index(kernel, summary.index("PMC counters")):]
 fetch = float(re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg\s+([\d.]+)", block).group(1))
 write = float(re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg\s+([\d.]+)", block).group(1))

@@ -114,7 +114,7 @@ struct shray_scene {
 
     // shray_render_batch_device: per-frame FrameViews travel through a small ring of slots
     // (pinned staging -> device); a slot is reused only after the launch that read it has finished
-    static constexpr int kBatchSlots = 4;
+    static constexpr int kBatchSlots = 16;
     FrameView *batch_staging = nullptr;   // pinned host, kBatchSlots * SHRAY_MAX_BATCH
     DeviceBuffer batch_views;             // device, same shape
     hipEvent_t batch_done[kBatchSlots] = {};
@@ -369,6 +369,42 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     return SHRAY_OK;
 }
 
+// The stack kernel reads its FrameViews from device memory (far fewer scalar registers held, and
+// spilled, than with the 480-byte view as a by-value kernel argument): `count` views travel through a
+// ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
+int launch_stack_views(shray_scene *scene, const FrameView *views, int count, float4 *d_out, size_t frame_stride,
+                       hipStream_t stream)
+{
+    if (views[0].total_patches == 0)
+        return SHRAY_OK;
+    if (!scene->batch_staging) {
+        const size_t bytes = sizeof(FrameView) * shray_scene::kBatchSlots * SHRAY_MAX_BATCH;
+        HIP_TRY(hipHostMalloc((void **)&scene->batch_staging, bytes, hipHostMallocDefault));
+        HIP_TRY(scene->batch_views.upload(nullptr, bytes));
+        for (int k = 0; k < shray_scene::kBatchSlots; k++)
+            HIP_TRY(hipEventCreateWithFlags(&scene->batch_done[k], hipEventDisableTiming));
+    }
+    const int slot = scene->batch_next;
+    scene->batch_next = (slot + 1) % shray_scene::kBatchSlots;
+    if (scene->batch_pending[slot])
+        HIP_TRY(hipEventSynchronize(scene->batch_done[slot]));   // rarely waits: the launch kBatchSlots launches ago
+    FrameView *staged = scene->batch_staging + (size_t)slot * SHRAY_MAX_BATCH;
+    FrameView *d_views = (FrameView *)scene->batch_views.p + (size_t)slot * SHRAY_MAX_BATCH;
+    memcpy(staged, views, sizeof(FrameView) * (size_t)count);
+    HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
+    bool all_metal = true;
+    for (int k = 0; k < count; k++)
+        all_metal = all_metal && !(views[k].diffuse_color[0] > 0.0f && views[k].diffuse_color[1] > 0.0f &&
+                                   views[k].diffuse_color[2] > 0.0f);
+    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream,
+                                            scene->stack_levels);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
+    scene->batch_pending[slot] = true;
+    return SHRAY_OK;
+}
+
 int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters *d_counters, hipStream_t stream)
 {
     FrameView fr = fr_in;
@@ -380,6 +416,8 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     if (s->kernel_id == 2 && s->packed_ok && !view)
         e = launch_persistent(s->view, fr, d_out, d_counters, stream, s->stack_levels,
                               (unsigned int *)s->work_counter.p, s->resident_blocks);
+    else if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
+        return launch_stack_views(s, &fr, 1, d_out, 0, stream);
     else if (s->kernel_id != 1 && s->packed_ok)
         e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else
@@ -674,8 +712,8 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     hipStream_t stream = (hipStream_t)hip_stream;
     char *out = (char *)d_rgba_out;
 
-    // anything but the stack kernel (or a single frame) runs as plain consecutive launches
-    if (count == 1 || scene->kernel_id != 0 || !scene->packed_ok || scene->patch_order.p) {
+    // anything but the stack kernel runs as plain consecutive launches
+    if (scene->kernel_id != 0 || !scene->packed_ok || scene->patch_order.p) {
         for (int k = 0; k < count; k++) {
             const int rc = launch(scene, views[k], (float4 *)(out + (size_t)k * frame_stride_bytes), nullptr, stream);
             if (rc)
@@ -683,34 +721,7 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
         }
         return SHRAY_OK;
     }
-    if (views[0].total_patches == 0)
-        return SHRAY_OK;
-
-    if (!scene->batch_staging) {
-        const size_t bytes = sizeof(FrameView) * shray_scene::kBatchSlots * SHRAY_MAX_BATCH;
-        HIP_TRY(hipHostMalloc((void **)&scene->batch_staging, bytes, hipHostMallocDefault));
-        HIP_TRY(scene->batch_views.upload(nullptr, bytes));
-        for (int k = 0; k < shray_scene::kBatchSlots; k++)
-            HIP_TRY(hipEventCreateWithFlags(&scene->batch_done[k], hipEventDisableTiming));
-    }
-    const int slot = scene->batch_next;
-    scene->batch_next = (slot + 1) % shray_scene::kBatchSlots;
-    if (scene->batch_pending[slot])
-        HIP_TRY(hipEventSynchronize(scene->batch_done[slot]));   // rarely waits: the launch four batches ago
-    FrameView *staged = scene->batch_staging + (size_t)slot * SHRAY_MAX_BATCH;
-    FrameView *d_views = (FrameView *)scene->batch_views.p + (size_t)slot * SHRAY_MAX_BATCH;
-    memcpy(staged, views.data(), sizeof(FrameView) * (size_t)count);
-    HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
-    bool all_metal = true;
-    for (const FrameView &v : views)
-        all_metal = all_metal && !(v.diffuse_color[0] > 0.0f && v.diffuse_color[1] > 0.0f && v.diffuse_color[2] > 0.0f);
-    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], all_metal, (float4 *)d_rgba_out,
-                                            (size_t)frame_stride_bytes / 16, stream, scene->stack_levels);
-    if (e != hipSuccess)
-        return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
-    scene->batch_pending[slot] = true;
-    return SHRAY_OK;
+    return launch_stack_views(scene, views.data(), count, (float4 *)d_rgba_out, (size_t)frame_stride_bytes / 16, stream);
 }
 
 int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, int channels, int64_t rank_stride_bytes,

@@ -289,12 +289,12 @@ def test_frame_batches_equal_single_launches(pkg, gpu, bunny):
     scene.set_kernel(0)
     # more batches in flight than the library has parameter slots
     nbytes = pkg.tracer.tile_buffer_bytes(W, H, None)
-    ring = torch.zeros(12, 2, nbytes // 4, dtype=torch.float32, device="cuda:0")
-    for j in range(12):
+    ring = torch.zeros(40, 2, nbytes // 4, dtype=torch.float32, device="cuda:0")
+    for j in range(40):
         scene.render_batch_into([frames[j % 3], frames[(j + 1) % 3]], W, H, 1, ring[j].data_ptr(), nbytes, stream, None)
     torch.cuda.synchronize()
     singles = [scene.render(frames[k], W, H, 1) for k in range(3)]
-    for j in range(12):
+    for j in range(40):
         assert np.array_equal(ring[j, 0].cpu().numpy().reshape(H, W, 4), singles[j % 3])
         assert np.array_equal(ring[j, 1].cpu().numpy().reshape(H, W, 4), singles[(j + 1) % 3])
 

@@ -67,12 +67,16 @@ def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
 
 
 def main():
+    global WIDTH, HEIGHT, SPP
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--width", type=int, default=WIDTH, help="frame width (default: the headline configuration)")
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel; --width 3840 --height 2160 --spp 16 is BASELINE configs[4]")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="independent frames (N > 1: launches) alternate over this many HIP streams (1 = strictly one at a time)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
@@ -80,6 +84,7 @@ def main():
                          "(default: the number of GPUs, so a launch always carries one frame's worth of pixels per GPU)")
     ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: gather RGBA instead of RGB (alpha is the constant 1)")
     args = ap.parse_args()
+    WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
 
     import torch
     import torch.distributed as dist
@@ -220,12 +225,14 @@ def main():
     if rank == 0:
         rays = WIDTH * HEIGHT * SPP * args.steps
         result = {
-            "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling",
+            "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling" if (WIDTH, HEIGHT, SPP) == (1920, 1080, 1)
+            else f"Mrays/s at {WIDTH}x{HEIGHT} {SPP}spp (bunny.trisrc)",
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
-                                   "2048x1024 HDR sky, 1920x1080, 1 spp, gold, 3 bounces (BASELINE configs[1])",
+                                   f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, gold, 3 bounces"
+                                   + (" (BASELINE configs[1])" if (WIDTH, HEIGHT, SPP) == (1920, 1080, 1) else ""),
                        "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "persistent"}[args.kernel],
                        "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu",
                        "frames_in_flight": lanes * batch, "frames_per_launch": batch, "streams": lanes,

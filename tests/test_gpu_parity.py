@@ -328,6 +328,31 @@ def test_frame_batches_equal_single_launches(pkg, gpu, bunny):
     assert np.array_equal(one[: nbytes // 4].cpu().numpy().reshape(H, W, 4), scene.render(mixed, W, H, 1))
 
 
+@pytest.mark.parametrize("rgb_wire", [True, False])
+def test_split_frame_object_on_one_gpu(pkg, gpu, bunny, rgb_wire):
+    """multigpu.DistributedFrame without a process group (one rank owns every tile): one launch for two
+    frames, pack, de-interleave kernel -- the frames must be those of direct full-frame renders."""
+    import torch
+    from shader_ray_amd import multigpu
+    world, desc, scene = bunny
+    W, H = 200, 136
+    frames = [world.frame_params(W, H, material=m) for m in (0, 6)]
+    split = multigpu.DistributedFrame(W, H, 32, 32, device="cuda:0", frames=2, rgb_wire=rgb_wire)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render_tiles(tile_set, out):
+        scene.render_batch_into(frames[: out.shape[0]], W, H, 1, out.data_ptr(), split.frame_stride_bytes, stream, tile_set)
+
+    got = split.render(render_tiles)
+    torch.cuda.synchronize()
+    assert got.shape == (2, H, W, 4)
+    for k in range(2):
+        assert np.array_equal(got[k].cpu().numpy(), scene.render(frames[k], W, H, 1)), k
+    short = split.render(render_tiles, count=1)
+    torch.cuda.synchronize()
+    assert short.shape == (1, H, W, 4) and np.array_equal(short[0].cpu().numpy(), scene.render(frames[0], W, H, 1))
+
+
 def test_error_paths(pkg, gpu, bunny, env_sky):
     N = pkg._native
     world, desc, scene = bunny

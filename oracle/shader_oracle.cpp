@@ -248,6 +248,23 @@ struct Ctx {
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
 uint32_t *g_visit_map = nullptr;
 
+// optional per-ray event trace (diagnostics, single-threaded renders only; oracle/tools/wave_sim.cpp reads it):
+// per sample, per traversal: 0xF0 then one byte per node visit = the number of triangle tests that visit ran
+struct VisitTrace {
+    uint8_t *bytes;
+    uint64_t capacity, length;
+    uint64_t *sample_offsets;   // [samples + 1]
+    uint64_t samples;
+};
+VisitTrace *g_trace = nullptr;
+inline void trace_byte(uint8_t b)
+{
+    if (g_trace && g_trace->length < g_trace->capacity)
+        g_trace->bytes[g_trace->length] = b;
+    if (g_trace)
+        g_trace->length++;
+}
+
 struct ray {   // fs:58-63
     vec3 P, D;
     vec3 dPdx, dDdx, dPdy, dDdy;
@@ -375,10 +392,12 @@ void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surfac
     const float zd = (theray.D.z > 0.0f) ? 4.0f : 0.0f;
     const float offset = (xd + yd + zd) * float(s.group_rows) * float(s.width);
 
+    trace_byte(0xF0);
     for (int i = 0; i < max_bvh_iterations; i++) {
         cx.c.node_visits++;
         group gg = get_group(cx, g, offset);
         range r = range_intersect_box(gg.boxmin, gg.boxmax, theray, prevr);
+        const uint64_t tests_before = cx.c.triangle_tests;
         if ((!range_is_empty(r)) && (r.t0 < hit.t)) {
             if (!gg.is_branch) {
                 for (float j = 0.0f; j < max_leaf_tests; j++) {
@@ -391,6 +410,7 @@ void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surfac
         } else {
             g = gg.miss_next;
         }
+        trace_byte((uint8_t)(cx.c.triangle_tests - tests_before));
         if (g >= terminator)
             return;
         if (i == max_bvh_iterations - 1) {   // fs:436-438, set_bad_hit(hit, 1, 0, 0) fs:162-166
@@ -730,6 +750,8 @@ void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float 
         const float oy = (float)bitreverse32((uint32_t)s) * 2.3283064365386963e-10f + 0.5f / (float)spp;
         const float u = ((float)px + ox) / (float)width;
         const float v = ((float)py + oy) / (float)height;
+        if (g_trace)
+            g_trace->sample_offsets[((size_t)py * width + px) * spp + s] = g_trace->length;
         const vec3 radiance = trace(cx, primary_ray(p, u, v));
         sum = (spp == 1) ? radiance : sum + radiance;
     }
@@ -828,6 +850,24 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
 
 // Diagnostics: when set, shray_oracle_render also writes node visits per pixel (width*height uint32).
 void shray_oracle_set_visit_map(uint32_t *map) { g_visit_map = map; }
+
+// Diagnostics: records the event trace of the next renders (call with threads = 1, whole frame, in pixel order);
+// sample_offsets needs width*height*spp + 1 entries.  shray_oracle_trace_end returns the bytes the trace needed.
+void shray_oracle_trace_begin(uint8_t *bytes, uint64_t capacity, uint64_t *sample_offsets, uint64_t samples)
+{
+    static VisitTrace trace;
+    trace = VisitTrace{bytes, capacity, 0, sample_offsets, samples};
+    g_trace = &trace;
+}
+uint64_t shray_oracle_trace_end()
+{
+    if (!g_trace)
+        return 0;
+    const uint64_t n = g_trace->length;
+    g_trace->sample_offsets[g_trace->samples] = n;
+    g_trace = nullptr;
+    return n;
+}
 
 // Pieces exposed for the known-answer tests.
 float shray_oracle_filmic(float c) { return filmic(c); }

@@ -36,6 +36,7 @@
 #ifndef SHADER_RAY_HIP_H
 #define SHADER_RAY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -183,6 +184,19 @@ int shray_scene_set_kernel(shray_scene *scene, int kernel_id);
  * raytracer.vs:56), alpha = 1 (raytracer.es.fs:676). */
 int shray_render(shray_scene *scene, const shray_frame_params *params,
                  int width, int height, int spp, float *rgba_out_host);
+/* shray_render is the blocking readback form (screenshot, ray.cpp:760): the frame is rendered into a device
+ * frame the scene keeps, then copied out on the scene's own stream.  When rgba_out_host is pinned host
+ * memory (shray_pinned_alloc, or any hipHostMalloc / hipHostRegister memory) the copy is one DMA at PCIe
+ * speed; pageable memory goes through the scene's pinned staging buffer in overlapped pieces.
+ *
+ * shray_render_host_async is the non-blocking form for frame loops: render + DMA into PINNED host memory
+ * are enqueued on hip_stream and the call returns; the frame is complete once the stream reaches that
+ * point (hipStreamSynchronize / an event).  One in-flight call per scene (it uses the scene's frame). */
+int shray_render_host_async(shray_scene *scene, const shray_frame_params *params,
+                            int width, int height, int spp, float *rgba_out_pinned, void *hip_stream);
+/* Pinned host memory for the two calls above. */
+int shray_pinned_alloc(size_t bytes, void **out_ptr);
+int shray_pinned_free(void *ptr);
 
 /* Asynchronous form: d_rgba_out is device memory on the scene's device,
  * hip_stream a hipStream_t (NULL = default stream).  tiles may be NULL.

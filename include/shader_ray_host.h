@@ -59,6 +59,10 @@ int shray_host_default_view(const shray_host_world *world, shray_host_view *view
 int shray_host_frame_params(shray_host_world *world, const shray_host_view *view, int width, int height,
                             shray_frame_params *params);
 
+/* trackball_motion() (ray.cpp:91-98): the rotation {angle, axis} after a mouse drag of (dx, dy) window
+ * fractions on top of `previous`; (0, 0) leaves *result untouched, as upstream. */
+int shray_host_trackball_motion(const float previous[4], float dx, float dy, float result[4]);
+
 /* load_background() (host/background.h): the reference's background argument (ray.cpp:1002-1075):
  * "r, g, b", "grid", "rrggbb" or a Radiance .hdr file.  *pixels (3 floats per pixel, row 0 =
  * bottom row) is malloc'ed; release it with shray_host_free_background. */

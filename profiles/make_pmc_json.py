@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turns a profiles/run_profile.sh summary (rocprofv3 kernel trace + separate --pmc passes of the default
+bench command) into the counter file bench.py reads for its roofline object:
+
+    python profiles/make_pmc_json.py <summary.txt> <out.json> [kernel name substring]
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports FETCH_SIZE and
+WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane loads as 64 bytes,
+so the read side is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from buildhash import kernel_source_hash  # noqa: E402
+
+summary_path, out_path = sys.argv[1], sys.argv[2]
+want = sys.argv[3] if len(sys.argv) > 3 else "trace_stack_batch_kernel<false, true, true>"
+text = open(summary_path).read()
+trace, pmc = text.split("== PMC counters", 1)
+avg_us = None
+for line in trace.splitlines():
+    if want in line:
+        avg_us = float(re.search(r"avg\s+([\d.]+)", line).group(1))
+        calls = int(re.search(r"calls\s+(\d+)", line).group(1))
+        break
+block = pmc[pmc.index(want):]
+nxt = re.search(r"\n(?=\S)", block[1:])
+block = block if not nxt else block[:nxt.start() + 1]
+vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+n=\s*\d+\s+avg\s+([\d.]+)", block, re.M)}
+fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
+out = {
+    "kernel": want,
+    "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_in_flight": 2},
+    "build_hash": kernel_source_hash(),
+    "kernel_trace_avg_us": avg_us, "kernel_trace_calls": calls,
+    "counters_per_launch": vals,
+    "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"),
+    "lane_util": (vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_INSTS_VALU"] * 64.0)) if "SQ_THREAD_CYCLES_VALU" in vals else None,
+    "hbm_bytes_per_launch": int((2 * fetch + write) * 1024) if fetch is not None and write is not None else None,
+    "hbm_note": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane loads) + WRITE_SIZE, KiB -> bytes, per launch",
+    "source": summary_path,
+}
+json.dump(out, open(out_path, "w"), indent=1)
+print(json.dumps(out))

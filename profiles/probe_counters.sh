@@ -4,7 +4,9 @@ set -u
 # ARGS="4 1" passes arguments to the script
 TAG=$1; SCRIPT=$2
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof_$TAG; mkdir -p "$OUT"
-export TMPDIR=/tmp; cd /tmp
+export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8   # before rocprofv3: its preloaded library initialises HIP ahead of bench.py
+cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/$SCRIPT ${ARGS:-} > "$OUT/trace.log" 2>&1
 i=0
 for GROUP in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \

@@ -89,6 +89,9 @@ HIP_SYMBOLS = [
     ("shray_scene_destroy", C.c_int, [C.c_void_p]),
     ("shray_scene_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
     ("shray_render", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, c_float_p]),
+    ("shray_render_host_async", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("shray_pinned_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("shray_pinned_free", C.c_int, [C.c_void_p]),
     ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
     ("shray_render_batch_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -108,6 +111,7 @@ HOST_SYMBOLS = [
     ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
     ("shray_host_default_view", C.c_int, [C.c_void_p, C.POINTER(HostView)]),
     ("shray_host_frame_params", C.c_int, [C.c_void_p, C.POINTER(HostView), C.c_int, C.c_int, C.POINTER(FrameParams)]),
+    ("shray_host_trackball_motion", C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]),
     ("shray_host_load_background", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_float_p)]),
     ("shray_host_free_background", None, [c_float_p]),
     ("shray_host_set_quiet", None, [C.c_int]),

@@ -99,8 +99,7 @@ struct DeviceBuffer {
 
 struct shray_scene {
     int device = 0;
-    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel, 2 = persistent kernel
-    int resident_blocks = 1024; // persistent kernel grid: CUs x resident workgroups per CU
+    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel
     bool packed_ok = false;     // link tables verified against the packed tree
     int stack_levels = 1;
 
@@ -108,7 +107,6 @@ struct shray_scene {
     DeviceBuffer packed_nodes, packed_tris;
     DeviceBuffer env;
     DeviceBuffer counters;
-    DeviceBuffer work_counter;
     DeviceBuffer patch_order;        // permutation of patch indices for the stack kernel (optional)
     uint32_t patch_order_count = 0;
 
@@ -121,10 +119,26 @@ struct shray_scene {
     bool batch_pending[kBatchSlots] = {};
     int batch_next = 0;
 
+    // shray_render / shray_render_host_async: the device frame and the pinned staging buffer are kept
+    // between calls (grown on demand), and the readback runs on the scene's own stream
+    DeviceBuffer frame;
+    size_t frame_bytes = 0;
+    void *staging = nullptr;
+    size_t staging_bytes = 0;
+    hipStream_t readback_stream = nullptr;
+    hipEvent_t piece_done[4] = {};
+
     SceneView view{};
 
     ~shray_scene()
     {
+        if (staging)
+            (void)hipHostFree(staging);
+        if (readback_stream)
+            (void)hipStreamDestroy(readback_stream);
+        for (hipEvent_t &e : piece_done)
+            if (e)
+                (void)hipEventDestroy(e);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -412,11 +426,7 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
-    const bool view = fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5;
-    if (s->kernel_id == 2 && s->packed_ok && !view)
-        e = launch_persistent(s->view, fr, d_out, d_counters, stream, s->stack_levels,
-                              (unsigned int *)s->work_counter.p, s->resident_blocks);
-    else if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
+    if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
         return launch_stack_views(s, &fr, 1, d_out, 0, stream);
     else if (s->kernel_id != 1 && s->packed_ok)
         e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
@@ -516,7 +526,6 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     HIP_TRY(s->objects.upload(desc->group_objects, ng * 8));
     HIP_TRY(s->hitmiss.upload(desc->group_hitmiss, (size_t)stride * 8 * 8));
     HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters) * kCounterShards));
-    HIP_TRY(s->work_counter.upload(nullptr, sizeof(unsigned int)));
 
     // packed layout for the stack kernel, if the tables describe a canonical threaded tree
     int depth = 0;
@@ -554,9 +563,6 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         s->view.exact_div_ok = coords_ok ? 1u : 0u;
         s->stack_levels = std::max(1, depth);
         s->packed_ok = true;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        s->resident_blocks = std::max(1, prop.multiProcessorCount) * persistent_blocks_per_cu(s->stack_levels);
     }
 
     SceneView &v = s->view;
@@ -637,8 +643,8 @@ int shray_scene_destroy(shray_scene *scene)
 
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
-    if (!scene || kernel_id < 0 || kernel_id > 2)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = persistent)", kernel_id);
+    if (!scene || kernel_id < 0 || kernel_id > 1)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded)", kernel_id);
     if (kernel_id != 1 && !scene->packed_ok)
         return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
                     "literal threaded kernel (1) can run it");
@@ -748,6 +754,32 @@ int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, i
     return SHRAY_OK;
 }
 
+namespace {
+int ensure_frame(shray_scene *scene, size_t bytes)
+{
+    if (scene->frame_bytes < bytes) {
+        HIP_TRY(scene->frame.upload(nullptr, bytes));
+        scene->frame_bytes = bytes;
+    }
+    if (!scene->readback_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&scene->readback_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : scene->piece_done)
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return SHRAY_OK;
+}
+
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();   // pageable memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+}   // namespace
+
 int shray_render(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
                  float *rgba_out_host)
 {
@@ -757,14 +789,82 @@ int shray_render(shray_scene *scene, const shray_frame_params *params, int width
     if (rc)
         return rc;
     HIP_TRY(hipSetDevice(scene->device));
-    DeviceBuffer frame;
     const size_t bytes = (size_t)width * height * 16;
-    HIP_TRY(frame.upload(nullptr, bytes));
-    rc = shray_render_device(scene, params, width, height, spp, nullptr, frame.p, nullptr);
+    rc = ensure_frame(scene, bytes);
     if (rc)
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(rgba_out_host, frame.p, bytes, hipMemcpyDeviceToHost));
+    hipStream_t stream = scene->readback_stream;
+    rc = shray_render_device(scene, params, width, height, spp, nullptr, scene->frame.p, stream);
+    if (rc)
+        return rc;
+    if (is_pinned_host(rgba_out_host)) {   // one DMA straight into the caller's buffer
+        HIP_TRY(hipMemcpyAsync(rgba_out_host, scene->frame.p, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SHRAY_OK;
+    }
+    // pageable destination: DMA into the pinned staging buffer in four pieces; the host copies piece k
+    // out while piece k + 1 is still crossing PCIe
+    if (scene->staging_bytes < bytes) {
+        if (scene->staging)
+            (void)hipHostFree(scene->staging);
+        scene->staging = nullptr;
+        scene->staging_bytes = 0;
+        HIP_TRY(hipHostMalloc(&scene->staging, bytes, hipHostMallocDefault));
+        scene->staging_bytes = bytes;
+    }
+    constexpr int kPieces = 4;
+    const size_t piece = ((bytes / kPieces) + 4095) & ~(size_t)4095;
+    for (int k = 0; k < kPieces; k++) {
+        const size_t off = std::min(bytes, piece * k), len = std::min(bytes, piece * (k + 1)) - off;
+        if (len)
+            HIP_TRY(hipMemcpyAsync((char *)scene->staging + off, (const char *)scene->frame.p + off, len, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(scene->piece_done[k], stream));
+    }
+    for (int k = 0; k < kPieces; k++) {
+        const size_t off = std::min(bytes, piece * k), len = std::min(bytes, piece * (k + 1)) - off;
+        HIP_TRY(hipEventSynchronize(scene->piece_done[k]));
+        if (len)
+            memcpy((char *)rgba_out_host + off, (const char *)scene->staging + off, len);
+    }
+    return SHRAY_OK;
+}
+
+int shray_render_host_async(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                            float *rgba_out_pinned, void *hip_stream)
+{
+    if (!scene || !rgba_out_pinned)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or output buffer is NULL");
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    if (!is_pinned_host(rgba_out_pinned))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_render_host_async needs pinned host memory (shray_pinned_alloc); "
+                    "use shray_render for pageable buffers");
+    const size_t bytes = (size_t)width * height * 16;
+    rc = ensure_frame(scene, bytes);
+    if (rc)
+        return rc;
+    rc = shray_render_device(scene, params, width, height, spp, nullptr, scene->frame.p, hip_stream);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(rgba_out_pinned, scene->frame.p, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    return SHRAY_OK;
+}
+
+int shray_pinned_alloc(size_t bytes, void **out_ptr)
+{
+    if (!out_ptr || bytes == 0)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_pinned_alloc: NULL result pointer or zero size");
+    *out_ptr = nullptr;
+    HIP_TRY(hipHostMalloc(out_ptr, bytes, hipHostMallocDefault));
+    return SHRAY_OK;
+}
+
+int shray_pinned_free(void *ptr)
+{
+    if (ptr)
+        HIP_TRY(hipHostFree(ptr));
     return SHRAY_OK;
 }
 
@@ -820,7 +920,7 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
 // Diagnostic build only (libshray_hip_diag.so, profiles/timeline.py): renders one frame with
 // the timed kernel and returns per wave 8 x uint64 {begin, end (100 MHz ticks), xcc<<32|hw_id, 0,
 // node-loop iterations, leaf-loop iterations, cycles in the node loop, cycles in the leaf loop}
-// (stack kernel) or 16 x uint64 (persistent kernel, see kernel_persistent.hip);
+// (stack kernel);
 // `stamps` must hold 64 * ceil(w/16) * ceil(h/16) values.
 int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
                          uint64_t *stamps)

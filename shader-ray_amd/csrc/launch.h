@@ -30,13 +30,6 @@ hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, 
                                  int height, int tile_w, int tile_h, size_t rank_stride, size_t frame_stride,
                                  hipStream_t stream);
 
-// persistent kernel: `work_counter` is one uint in device memory (zeroed on the stream before
-// the launch), `resident_blocks` the number of 256-thread workgroups the device keeps resident
-hipError_t launch_persistent(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters,
-                             hipStream_t stream, int stack_levels, unsigned int *work_counter, int resident_blocks);
-// resident 256-thread workgroups per CU for the persistent kernel at this LDS size
-int persistent_blocks_per_cu(int stack_levels);
-
 // Compares div_by_constant (exact_div.h) with true division on `pairs` pseudo-random
 // operand pairs drawn from the admitted ranges; *mismatches receives the count.
 hipError_t launch_division_selftest(unsigned long long pairs, unsigned long long seed,

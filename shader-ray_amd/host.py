@@ -45,9 +45,12 @@ class World:
     def flatten(self, data_texture_width: int = 2048) -> N.SceneDesc:
         """`get_shader_data` (reference world.cpp:298).  The returned descriptor points
         into memory owned by this World."""
+        if self._desc is not None and self._desc.data_texture_width == data_texture_width:
+            return self._desc
         desc = N.SceneDesc()
         if self._lib.shray_host_flatten(self._handle, data_texture_width, C.byref(desc)) != 0:
-            raise RuntimeError("get_shader_data failed")
+            raise RuntimeError("get_shader_data failed (tree deeper than the 64-entry link stack?)")
+        desc._owner = self   # the arrays live in the C-side world: keep it alive as long as the descriptor
         self._desc = desc
         return desc
 
@@ -94,6 +97,12 @@ class World:
         if self._lib.shray_host_frame_params(self._handle, C.byref(view), width, height, C.byref(params)) != 0:
             raise RuntimeError("frame parameter computation failed")
         return params
+
+
+def trackball_motion(rotation, dx: float, dy: float):
+    """ray.cpp:91-98: `rotation` (a 4-float ctypes array of a HostView) after a drag by (dx, dy), in place."""
+    N.load_host().shray_host_trackball_motion(rotation, dx, dy, rotation)
+    return rotation
 
 
 def load_background(spec: str) -> np.ndarray:

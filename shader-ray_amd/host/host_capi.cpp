@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "background.h"
 #include "bvh.h"
@@ -15,7 +16,7 @@ bool g_host_quiet = false;
 
 struct shray_host_world {
     world_ptr w;
-    std::unique_ptr<scene_shader_data> flat;
+    std::vector<std::unique_ptr<scene_shader_data>> flat;   // every flattening handed out stays valid until the world is freed
     bvh_build_stats stats;
     double load_seconds = 0;
 };
@@ -67,9 +68,12 @@ int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width,
 {
     if (!world || !desc || data_texture_width == 0)
         return -1;
-    world->flat.reset(new scene_shader_data);
-    scene_shader_data &d = *world->flat;
-    get_shader_data(world->w, d, data_texture_width);
+    std::unique_ptr<scene_shader_data> fresh(new scene_shader_data);
+    get_shader_data(world->w, *fresh, data_texture_width);
+    if (!fresh->links_complete)
+        return -1;   // upstream asserts here (world.cpp:228): never hand out half-threaded link tables
+    world->flat.push_back(std::move(fresh));
+    scene_shader_data &d = *world->flat.back();
 
     memset(desc, 0, sizeof(*desc));
     desc->struct_size = (uint32_t)sizeof(*desc);
@@ -106,6 +110,15 @@ int shray_host_default_view(const shray_host_world *world, shray_host_view *view
     view->which = s.which;
     view->which_material = s.which_material;
     view->which_diffuse_color = s.which_diffuse_color;
+    return 0;
+}
+
+int shray_host_trackball_motion(const float previous[4], float dx, float dy, float result[4])
+{
+    if (!previous || !result)
+        return -1;
+    float prev[4] = {previous[0], previous[1], previous[2], previous[3]};
+    trackball_motion(prev, dx, dy, result);
     return 0;
 }
 

@@ -266,8 +266,10 @@ void get_shader_data(world_ptr w, scene_shader_data &data, unsigned int width)
             t.join();
     }
     for (int code = 0; code < kDirectionCodes; code++) {
-        if (!complete[code])
+        if (!complete[code]) {
             fprintf(stderr, "hitmiss: tree deeper than %d, direction table %d is incomplete\n", kLinkStackCapacity, code);
+            data.links_complete = false;
+        }
     }
     host_info("hitmiss: %f seconds\n", seconds_since(then));
 }

@@ -71,6 +71,10 @@ struct scene_shader_data {
     float *group_hitmiss;                 // 8 tables of float2 (hit, miss); 2147483648 terminates
     float *group_objects;                 // float2 (start, count); 0,0 for branches
 
+    // not upstream: false when a link table could not be threaded (tree deeper than the 64-entry link stack
+    // of world.cpp:228, where upstream asserts); such arrays must not be rendered
+    bool links_complete = true;
+
     scene_shader_data();
     ~scene_shader_data();
     scene_shader_data(const scene_shader_data &) = delete;

@@ -7,6 +7,7 @@
 //                              half, light for the second, cycling the material every 25 frames), render
 //                              `frames` frames, print the reference's benchmark histogram (the 'B' key,
 //                              ray.cpp:1096-1131: 10 buckets of frame time / fps) and save the last frame
+//                [-f prefix]   also dump every frame as raw RGBA float32 to <prefix>NNN.rgba (row 0 = bottom)
 //
 // background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
 // (host/background.cpp; the reference decodes image files through FreeImagePlus).
@@ -31,7 +32,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     int width = 512, height = 512, material = 0, diffuse = 0, spp = 1, frames = 1;
-    std::string out = "color.ppm";
+    std::string out = "color.ppm", dump_prefix;
     for (int i = 3; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "-o")) out = argv[i + 1];
         else if (!strcmp(argv[i], "-w")) width = atoi(argv[i + 1]);
@@ -40,6 +41,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-d")) diffuse = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-s")) spp = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-n")) frames = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "-f")) dump_prefix = argv[i + 1];
     }
 
     world_ptr world = load_world(argv[1]);
@@ -83,7 +85,12 @@ int main(int argc, char **argv)
     shray_frame_params params;
     make_frame_params(world, view, width, height, &params);
 
-    std::vector<float> rgba((size_t)width * height * 4);
+    // the frame lands in pinned host memory: shray_render then reads it back with one DMA at PCIe speed
+    float *rgba = nullptr;
+    if (shray_pinned_alloc((size_t)width * height * 16, (void **)&rgba) != SHRAY_OK) {
+        fprintf(stderr, "pinned allocation failed: %s\n", shray_last_error());
+        return EXIT_FAILURE;
+    }
     std::vector<float> frame_seconds;
     for (int frame = 0; frame < std::max(frames, 1); frame++) {
         if (frames > 1) {
@@ -96,11 +103,21 @@ int main(int argc, char **argv)
             make_frame_params(world, view, width, height, &params);
         }
         const auto then = std::chrono::steady_clock::now();
-        if (shray_render(scene, &params, width, height, spp, rgba.data()) != SHRAY_OK) {
+        if (shray_render(scene, &params, width, height, spp, rgba) != SHRAY_OK) {
             fprintf(stderr, "render failed: %s\n", shray_last_error());
             return EXIT_FAILURE;
         }
         frame_seconds.push_back(std::chrono::duration<float>(std::chrono::steady_clock::now() - then).count());
+        if (!dump_prefix.empty()) {
+            char name[1024];
+            snprintf(name, sizeof(name), "%s%03d.rgba", dump_prefix.c_str(), frame);
+            FILE *df = fopen(name, "wb");
+            if (!df || fwrite(rgba, 16, (size_t)width * height, df) != (size_t)width * height) {
+                fprintf(stderr, "cannot write %s\n", name);
+                return EXIT_FAILURE;
+            }
+            fclose(df);
+        }
     }
     if (frames <= 1) {
         fprintf(stderr, "%dx%d, %d spp: %.3f ms including the copy to host\n", width, height, spp, frame_seconds[0] * 1e3);
@@ -136,6 +153,7 @@ int main(int argc, char **argv)
         fwrite(row.data(), 3, width, fp);
     }
     fclose(fp);
+    shray_pinned_free(rgba);
     shray_scene_destroy(scene);
     return EXIT_SUCCESS;
 }

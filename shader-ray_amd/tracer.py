@@ -56,6 +56,17 @@ class Scene:
                                        out.ctypes.data_as(N.c_float_p)))
         return out
 
+    def render_to_pinned(self, params: N.FrameParams, width: int, height: int, spp: int, pinned: "PinnedFrame",
+                         stream_ptr: int = 0, wait: bool = True):
+        """Render + DMA into pinned host memory on a HIP stream (shray_render_host_async).  With wait=False
+        the caller synchronises the stream before reading `pinned.array`."""
+        N.check(self._lib.shray_render_host_async(self._handle, C.byref(params), width, height, spp,
+                                                  C.c_void_p(pinned.ptr), C.c_void_p(stream_ptr)))
+        if wait:
+            import torch
+            torch.cuda.synchronize()
+        return pinned.array
+
     def render_counters(self, params: N.FrameParams, width: int, height: int, spp: int = 1, want_image: bool = True):
         out = np.empty((height, width, 4), dtype=np.float32) if want_image else None
         counters = N.Counters()
@@ -82,6 +93,30 @@ class Scene:
             self._handle, array, count, width, height, spp,
             C.byref(tiles) if tiles is not None else None, C.c_void_p(out_ptr), frame_stride_bytes,
             C.c_void_p(stream_ptr)))
+
+
+class PinnedFrame:
+    """RGBA float32 [height, width, 4] in pinned host memory (shray_pinned_alloc): the destination of the
+    PCIe-speed readback forms."""
+
+    def __init__(self, width: int, height: int):
+        self._lib = N.load_hip()
+        p = C.c_void_p()
+        N.check(self._lib.shray_pinned_alloc(width * height * 16, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_float * (width * height * 4)).from_address(self.ptr)).reshape(height, width, 4)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.shray_pinned_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tile_buffer_bytes(width: int, height: int, tiles: N.TileSet | None) -> int:

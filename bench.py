@@ -248,7 +248,7 @@ def main():
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
                                    f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, gold, 3 bounces"
                                    + (" (BASELINE configs[1])" if (WIDTH, HEIGHT, SPP) == (1920, 1080, 1) else ""),
-                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded"}[args.kernel],
+                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "pool"}[args.kernel],
                        "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu",
                        "frames_in_flight": lanes * batch, "frames_per_launch": batch, "streams": lanes,
                        "wire": ("rgb32f" if not args.rgba_wire else "rgba32f") if distributed else None},

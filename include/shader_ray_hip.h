@@ -175,8 +175,9 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene);
 int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height);
 int shray_scene_destroy(shray_scene *scene);
 
-/* Kernel selection: 0 = default (fastest parity-exact kernel),
- * 1 = literal threaded hit/miss-table traversal over the reference arrays. */
+/* Kernel selection: 0 = per-ray LDS stack kernel (default), 1 = literal threaded hit/miss-table traversal
+ * over the reference arrays, 2 = pool kernel (a workgroup's waves merge their live rays while they
+ * traverse: for divergent scenes).  All three produce bit-identical frames. */
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id);
 
 /* Render ----------------------------------------------------------------- */
@@ -187,7 +188,7 @@ int shray_render(shray_scene *scene, const shray_frame_params *params,
 /* shray_render is the blocking readback form (screenshot, ray.cpp:760): the frame is rendered into a device
  * frame the scene keeps, then copied out on the scene's own stream.  When rgba_out_host is pinned host
  * memory (shray_pinned_alloc, or any hipHostMalloc / hipHostRegister memory) the copy is one DMA at PCIe
- * speed; pageable memory goes through the scene's pinned staging buffer in overlapped pieces.
+ * speed; pageable memory is staged by the HIP runtime.
  *
  * shray_render_host_async is the non-blocking form for frame loops: render + DMA into PINNED host memory
  * are enqueued on hip_stream and the call returns; the frame is complete once the stream reaches that

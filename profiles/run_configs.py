@@ -13,7 +13,9 @@ import torch
 from __graft_entry__ import load_package
 import helpers
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+KERNEL = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ONLY = sys.argv[3].split(",") if len(sys.argv) > 3 else None   # e.g. "2,4": config numbers to run
 pkg = load_package()
 env = pkg.scenes.environment_hdr_sky(2048)
 stream = torch.cuda.current_stream().cuda_stream
@@ -21,6 +23,9 @@ results = []
 
 
 def run(name, world, scene, params, W, H, spp, reps):
+    if ONLY and name.split(":")[0].split()[0] not in ONLY:
+        return
+    scene.set_kernel(KERNEL)
     out = torch.empty(H * W * 4, dtype=torch.float32, device="cuda")
     for _ in range(2):
         scene.render_into(params, W, H, spp, out.data_ptr(), stream)
@@ -34,7 +39,7 @@ def run(name, world, scene, params, W, H, spp, reps):
     ms = a.elapsed_time(b) / reps
     _, counters = scene.render_counters(params, W, H, spp, want_image=False)
     algo = pkg.tracer.algorithmic_bytes(counters, W * H)
-    row = {"config": name, "width": W, "height": H, "spp": spp, "ms_per_frame": round(ms, 4),
+    row = {"config": name, "kernel": KERNEL, "width": W, "height": H, "spp": spp, "ms_per_frame": round(ms, 4),
            "mrays_per_s": round(W * H * spp / ms / 1e3, 1), "algorithmic_gb_per_s": round(algo / ms / 1e6, 1),
            "bytes_per_ray": round(algo / (W * H * spp), 1), "bad_hit_fraction": counters["bad_hits"] / counters["samples"],
            "counters": counters}
@@ -55,4 +60,4 @@ print("1M-triangle scene loaded: %d triangles, %d nodes, depth %d (%.1f s since 
     big.triangle_count, big.info.node_count, big.info.max_level, time.time() - t0), flush=True)
 scene = pkg.Scene(big.flatten(), env, device=0)
 run("4: 1M-triangle OBJ 1920x1080 4 spp gold", big, scene, big.frame_params(1920, 1080, material=0), 1920, 1080, 4, 5)
-json.dump(results, open(os.path.join(ROOT, "profiles", f"{tag}_configs.json"), "w"), indent=1)
+json.dump(results, open(os.path.join(ROOT, "gpurun_out", f"{tag}_configs_k{KERNEL}.json"), "w"), indent=1)

@@ -99,7 +99,7 @@ struct DeviceBuffer {
 
 struct shray_scene {
     int device = 0;
-    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel
+    int kernel_id = 0;          // 0 = stack kernel, 1 = literal threaded kernel, 2 = pool kernel (waves merge)
     bool packed_ok = false;     // link tables verified against the packed tree
     int stack_levels = 1;
 
@@ -119,26 +119,18 @@ struct shray_scene {
     bool batch_pending[kBatchSlots] = {};
     int batch_next = 0;
 
-    // shray_render / shray_render_host_async: the device frame and the pinned staging buffer are kept
-    // between calls (grown on demand), and the readback runs on the scene's own stream
+    // shray_render / shray_render_host_async: the device frame is kept between calls (grown on demand),
+    // and the blocking form's readback runs on the scene's own stream
     DeviceBuffer frame;
     size_t frame_bytes = 0;
-    void *staging = nullptr;
-    size_t staging_bytes = 0;
     hipStream_t readback_stream = nullptr;
-    hipEvent_t piece_done[4] = {};
 
     SceneView view{};
 
     ~shray_scene()
     {
-        if (staging)
-            (void)hipHostFree(staging);
         if (readback_stream)
             (void)hipStreamDestroy(readback_stream);
-        for (hipEvent_t &e : piece_done)
-            if (e)
-                (void)hipEventDestroy(e);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -410,8 +402,12 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
     for (int k = 0; k < count; k++)
         all_metal = all_metal && !(views[k].diffuse_color[0] > 0.0f && views[k].diffuse_color[1] > 0.0f &&
                                    views[k].diffuse_color[2] > 0.0f);
-    const hipError_t e = launch_stack_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream,
-                                            scene->stack_levels);
+    bool plain_view = true;   // the pool kernel renders which == 0 frames; the shader's debug views stay on the stack kernel
+    for (int k = 0; k < count; k++)
+        plain_view = plain_view && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
+    const hipError_t e = (scene->kernel_id == 2 && plain_view)
+        ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
+        : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
@@ -428,6 +424,9 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     hipError_t e;
     if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
         return launch_stack_views(s, &fr, 1, d_out, 0, stream);
+    else if (s->kernel_id == 2 && s->packed_ok && !fr.patch_order &&
+             !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5))
+        e = launch_pool(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else if (s->kernel_id != 1 && s->packed_ok)
         e = launch_stack(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else
@@ -643,8 +642,8 @@ int shray_scene_destroy(shray_scene *scene)
 
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
-    if (!scene || kernel_id < 0 || kernel_id > 1)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded)", kernel_id);
+    if (!scene || kernel_id < 0 || kernel_id > 2)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = pool)", kernel_id);
     if (kernel_id != 1 && !scene->packed_ok)
         return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
                     "literal threaded kernel (1) can run it");
@@ -719,7 +718,7 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     char *out = (char *)d_rgba_out;
 
     // anything but the stack kernel runs as plain consecutive launches
-    if (scene->kernel_id != 0 || !scene->packed_ok || scene->patch_order.p) {
+    if (scene->kernel_id == 1 || !scene->packed_ok || scene->patch_order.p) {
         for (int k = 0; k < count; k++) {
             const int rc = launch(scene, views[k], (float4 *)(out + (size_t)k * frame_stride_bytes), nullptr, stream);
             if (rc)
@@ -761,11 +760,8 @@ int ensure_frame(shray_scene *scene, size_t bytes)
         HIP_TRY(scene->frame.upload(nullptr, bytes));
         scene->frame_bytes = bytes;
     }
-    if (!scene->readback_stream) {
+    if (!scene->readback_stream)
         HIP_TRY(hipStreamCreateWithFlags(&scene->readback_stream, hipStreamNonBlocking));
-        for (hipEvent_t &e : scene->piece_done)
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     return SHRAY_OK;
 }
 
@@ -802,30 +798,9 @@ int shray_render(shray_scene *scene, const shray_frame_params *params, int width
         HIP_TRY(hipStreamSynchronize(stream));
         return SHRAY_OK;
     }
-    // pageable destination: DMA into the pinned staging buffer in four pieces; the host copies piece k
-    // out while piece k + 1 is still crossing PCIe
-    if (scene->staging_bytes < bytes) {
-        if (scene->staging)
-            (void)hipHostFree(scene->staging);
-        scene->staging = nullptr;
-        scene->staging_bytes = 0;
-        HIP_TRY(hipHostMalloc(&scene->staging, bytes, hipHostMallocDefault));
-        scene->staging_bytes = bytes;
-    }
-    constexpr int kPieces = 4;
-    const size_t piece = ((bytes / kPieces) + 4095) & ~(size_t)4095;
-    for (int k = 0; k < kPieces; k++) {
-        const size_t off = std::min(bytes, piece * k), len = std::min(bytes, piece * (k + 1)) - off;
-        if (len)
-            HIP_TRY(hipMemcpyAsync((char *)scene->staging + off, (const char *)scene->frame.p + off, len, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(scene->piece_done[k], stream));
-    }
-    for (int k = 0; k < kPieces; k++) {
-        const size_t off = std::min(bytes, piece * k), len = std::min(bytes, piece * (k + 1)) - off;
-        HIP_TRY(hipEventSynchronize(scene->piece_done[k]));
-        if (len)
-            memcpy((char *)rgba_out_host + off, (const char *)scene->staging + off, len);
-    }
+    // pageable destination: the runtime stages it through its own pinned buffers
+    HIP_TRY(hipMemcpyAsync(rgba_out_host, scene->frame.p, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return SHRAY_OK;
 }
 

@@ -24,6 +24,13 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
 
+// kernel id 2 (kernel_pool.hip): the workgroup's rays as a pool whose waves merge during the traversal;
+// which == 0 frames only.  Same argument conventions as the stack kernel's launchers.
+hipError_t launch_pool(const SceneView &sc, const FrameView &fr, float4 *out, DeviceCounters *counters, hipStream_t stream,
+                       int stack_levels);
+hipError_t launch_pool_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
+                             float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
+
 // rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,
 // frame_stride between a rank's consecutive frames
 hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, int frames, int channels, int width,

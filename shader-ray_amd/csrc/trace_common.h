@@ -358,27 +358,29 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
     return s;
 }
 
-// One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four
-// 8x8 wave tiles so that the 64 rays of a wave stay spatially coherent.
-// ONE_SAMPLE / METAL: instances for spp == 1 and for a zero diffuse colour (checked by the launcher):
-// no sample loop, no radiance sum, no diffuse branch -- fewer live registers across the traversal.
-template <class Traversal, bool COUNT, bool DIFF = false, bool ONE_SAMPLE = false, bool METAL = false>
-__device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
-                                             DeviceCounters *counters, Traversal &trav)
+// the counting twins: a wave's tallies go to one of kCounterShards copies (the host sums them)
+__device__ __forceinline__ void add_counters(const RayCounters &rc, DeviceCounters *counters)
 {
-    const unsigned int patch = fr.patch_order ? fr.patch_order[blockIdx.x] : blockIdx.x;
+    const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
+                                  rc.env_lookups, rc.traversals, rc.bad_hits};
+    unsigned long long *dst = &counters[blockIdx.x % kCounterShards].node_visits;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const unsigned long long s = wave_sum(vals[k]);
+        if ((threadIdx.x & 63u) == 0 && s)
+            atomicAdd(dst + k, s);
+    }
+}
+
+// Which pixel a thread renders and where it goes: workgroup `patch` is a 16x16 pixel patch (four 8x8 wave
+// tiles) of the whole frame (row-major output) or of the launch's k-th owned tile (packed output).
+__device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int patch, int &px, int &py, size_t &out_index,
+                                             bool &store, bool &inside)
+{
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#ifdef SHRAY_DIAGNOSTICS
-    // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a
-    // buffer nothing else reads
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-#endif
     const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
     const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
-
-    int px, py;
-    size_t out_index;
-    bool store = true;
+    store = true;
     if (fr.tile_stride == 0) {
         px = (int)(patch % (unsigned int)fr.patches_x) * 16 + lx;
         py = (int)(patch / (unsigned int)fr.patches_x) * 16 + ly;
@@ -395,7 +397,28 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
         py = ty * fr.tile_h + tly;
         out_index = (size_t)k * fr.tile_w * fr.tile_h + (size_t)tly * fr.tile_w + tlx;
     }
-    const bool inside = px < fr.width && py < fr.height;
+    inside = px < fr.width && py < fr.height;
+}
+
+// One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four
+// 8x8 wave tiles so that the 64 rays of a wave stay spatially coherent.
+// ONE_SAMPLE / METAL: instances for spp == 1 and for a zero diffuse colour (checked by the launcher):
+// no sample loop, no radiance sum, no diffuse branch -- fewer live registers across the traversal.
+template <class Traversal, bool COUNT, bool DIFF = false, bool ONE_SAMPLE = false, bool METAL = false>
+__device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
+                                             DeviceCounters *counters, Traversal &trav)
+{
+    const unsigned int patch = fr.patch_order ? fr.patch_order[blockIdx.x] : blockIdx.x;
+#ifdef SHRAY_DIAGNOSTICS
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a
+    // buffer nothing else reads
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    int px, py;
+    size_t out_index;
+    bool store, inside;
+    locate_pixel(fr, patch, px, py, out_index, store, inside);
 
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
     V3 result = mk(0, 0, 0);
@@ -472,17 +495,8 @@ __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameVie
             tl[4 + k] = trav.diag_tally[k];
     }
 #endif
-    if (COUNT) {
-        const unsigned int vals[7] = {rc.node_visits, rc.leaf_visits, rc.triangle_tests, rc.shaded_hits,
-                                      rc.env_lookups, rc.traversals, rc.bad_hits};
-        unsigned long long *dst = &counters[blockIdx.x % kCounterShards].node_visits;
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const unsigned long long s = wave_sum(vals[k]);
-            if (lane == 0 && s)
-                atomicAdd(dst + k, s);
-        }
-    }
+    if (COUNT)
+        add_counters(rc, counters);
 }
 
 }   // namespace shray

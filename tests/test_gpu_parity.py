@@ -17,7 +17,7 @@ from helpers import assert_images_match, default_params, single_leaf_scene
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KERNELS = [0, 1]   # 0 = packed stack kernel, 1 = literal threaded kernel
+KERNELS = [0, 1, 2]   # 0 = packed stack kernel, 1 = literal threaded kernel, 2 = pool kernel (waves merge mid-traversal)
 
 
 @pytest.fixture(scope="module")

@@ -148,26 +148,35 @@ def main():
     # N > 1: a rank's share of one 1080p frame is latency-bound (its long-running waves take ~0.5 ms
     # wherever they land), so a launch carries `batch` consecutive frames (shray_render_batch_device) and
     # one gather moves them all: fewer, larger collectives, and the GPU stays full.
-    batch = max(1, min(64, args.frames_per_launch or world_size)) if distributed else 1
+    # N = 1: the frame loop hands the C ABI two frames per launch (shray_render_batch_device, the throughput form of
+    # the frame loop, ray.cpp:1096-1131); --frames-per-launch 1 --frames-in-flight 1 is strictly one frame at a time
+    batch = max(1, min(64, args.frames_per_launch or (world_size if distributed else 2)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
-    frame_outs = [torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
+    frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     splits = [multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device, always_gather=True,
                                         stage_through_host=(backend != "nccl"), frames=batch,
                                         rgb_wire=not args.rgba_wire) for _ in range(lanes)] if distributed else None
     trials = max(1, args.trials)
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps * trials)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps * trials)]
+    starts, stops, launch_frames = [], [], []
     torch.cuda.synchronize()
 
-    def step(k, timed=None):
-        """frame k, one launch (single-GPU path); timed = index of the trial whose events bracket the launch"""
-        lane = k % lanes
+    def step(j, count, timed=None):
+        """launch j of the single-GPU path: `count` consecutive frames; timed: HIP events bracket the launch"""
+        lane = j % lanes
         st = streams[lane]
         if timed is not None:
-            starts[timed * args.steps + k].record(st)
-        scene.render_into(params, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            starts.append(a)
+            stops.append(b)
+            launch_frames.append(count)
+            a.record(st)
+        if count == 1:
+            scene.render_into(params, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
+        else:
+            scene.render_batch_into([params] * count, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), HEIGHT * WIDTH * 16,
+                                    st.cuda_stream, None)
         if timed is not None:
-            stops[timed * args.steps + k].record(st)
+            b.record(st)
         return frame_outs[lane]
 
     def launch(j, count):
@@ -186,8 +195,12 @@ def main():
         """exactly `frames` frames; returns what the last launch produced"""
         last = None
         if not distributed:
-            for k in range(frames):
-                last = step(k, timed)
+            done = j = 0
+            while done < frames:
+                count = min(batch, frames - done)
+                last = step(j, count, timed)
+                done += count
+                j += 1
             return last
         done = j = 0
         while done < frames:
@@ -270,10 +283,10 @@ def main():
         # launch went to.  With frames_in_flight > 1 two launches share the GPU, so each lasts longer than it
         # would alone while the pair finishes sooner: rates below use WALL time, not per-launch time.
         kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        avg_ms = sum(kernel_ms) / len(kernel_ms)   # per LAUNCH (a launch carries `batch` frames)
         _, counters = scene.render_counters(params, WIDTH, HEIGHT, SPP, want_image=False)
         algo_bytes = pkg.tracer.algorithmic_bytes(counters, WIDTH * HEIGHT, normals_fp16=True)
-        launches_per_s = args.steps / elapsed
+        frames_per_s = args.steps / elapsed
         # hardware counters of the dominant kernel come from a committed rocprofv3 --pmc run of THIS command
         # (they cannot be read from inside the process); used only if they were taken on this workload
         pmc, pmc_note = None, "no counter file"
@@ -282,7 +295,8 @@ def main():
             from buildhash import kernel_source_hash
             cand = json.load(open(os.path.join(ROOT, PMC_FILE)))
             wl = cand["workload"]
-            if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"]) == (WIDTH, HEIGHT, SPP, args.kernel) and cand["valu_insts_per_launch"]:
+            if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"], wl.get("frames_per_launch", 1)) == \
+                    (WIDTH, HEIGHT, SPP, args.kernel, batch) and cand["valu_insts_per_launch"]:
                 pmc = cand
                 pmc_note = PMC_FILE + (" (same kernel sources as this build)" if cand["build_hash"] == kernel_source_hash()
                                        else " (STALE: measured on different kernel sources than this build)")
@@ -296,24 +310,25 @@ def main():
                 "why": "the scene + environment working set (32 MB) is cache-resident: the kernel is bound by VALU issue, "
                        "not by HBM (DESIGN.md section 4.4); HBM use is reported as hbm_frac"}
         if pmc:
-            ginst = pmc["valu_insts_per_launch"] * launches_per_s / 1e9
+            fpl = pmc["workload"].get("frames_per_launch", 1)   # the profiled launches carried this many frames each
+            ginst = pmc["valu_insts_per_launch"] / fpl * frames_per_s / 1e9
             roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 5),
                          "lane_util": round(pmc["lane_util"], 4) if pmc.get("lane_util") else None,
                          "useful_frac": round(ginst / VALU_PEAK_GINST * pmc["lane_util"], 5) if pmc.get("lane_util") else None,
-                         "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                         "valu_insts_per_frame": pmc["valu_insts_per_launch"] / fpl,
                          "profiled_kernel_us": pmc.get("kernel_trace_avg_us")})
             if pmc.get("hbm_bytes_per_launch"):
-                hbm_gbs = pmc["hbm_bytes_per_launch"] * launches_per_s / 1e9
-                roof.update({"traffic": pmc["hbm_bytes_per_launch"], "hbm_gbs": round(hbm_gbs, 2),
+                hbm_gbs = pmc["hbm_bytes_per_launch"] / fpl * frames_per_s / 1e9
+                roof.update({"traffic": pmc["hbm_bytes_per_launch"], "traffic_frames": fpl, "hbm_gbs": round(hbm_gbs, 2),
                              "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 5)})
-        algo_gbs = algo_bytes * launches_per_s / 1e9
+        algo_gbs = algo_bytes * frames_per_s / 1e9
         roof["algorithmic_cacheless"] = {
-            "bytes_per_launch": algo_bytes, "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
+            "bytes_per_frame": algo_bytes, "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
             "gbs": round(algo_gbs, 2), "x_hbm_peak": round(algo_gbs / HBM_PEAK_GBS, 4),
-            "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x launches / wall time; these bytes are served by "
+            "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x frames / wall time; these bytes are served by "
                     "L1/L2, so this is not a bound and may exceed the HBM peak"}
         roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
-                     "concurrent_launches": lanes})
+                     "concurrent_launches": lanes, "frames_per_launch": batch})
         result["roofline"] = roof
         result["counters"] = counters
         # the C ABI's host-buffer forms, PCIe-inclusive, for the record (never `value`): the blocking call into

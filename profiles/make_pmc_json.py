@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from buildhash import kernel_source_hash  # noqa: E402
 
 summary_path, out_path = sys.argv[1], sys.argv[2]
-want = sys.argv[3] if len(sys.argv) > 3 else "trace_stack_batch_kernel<false, true, true>"
+want = sys.argv[3] if len(sys.argv) > 3 else "trace_stack_batch_kernel<true, true, false>"
+frames_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 text = open(summary_path).read()
 trace, pmc = text.split("== PMC counters", 1)
 avg_us = None
@@ -32,7 +33,8 @@ vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+n=\s*\d
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 out = {
     "kernel": want,
-    "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_in_flight": 2},
+    "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_per_launch": frames_per_launch,
+                 "streams": 2},
     "build_hash": kernel_source_hash(),
     "kernel_trace_avg_us": avg_us, "kernel_trace_calls": calls,
     "counters_per_launch": vals,

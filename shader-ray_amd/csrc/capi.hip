@@ -375,6 +375,22 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     return SHRAY_OK;
 }
 
+// Which leaf stage the gold-class (zero diffuse colour) instances of the stack kernel run.  Dealing a parked
+// ray's triangles to the wave's idle lanes shortens divergent waves -- fewer instructions, one memory round
+// trip per leaf instead of up to ten -- but the instance holds a second ray's worth of registers: six waves per
+// SIMD instead of seven.  Measured on MI355X (profiles/r02/leaf_stage_ab.txt):
+//   * trees larger than an XCD's L2 share (the 1M-triangle scene, 9.4 MB of nodes): rays diverge, the walk is
+//     latency-bound, dealing wins by 10-18 %;
+//   * one spp == 1 frame per launch (latency): the frame ends with a tail of divergent waves, dealing wins by 11 %;
+//   * a cache-resident scene rendered for throughput (several frames per launch, or many samples per pixel):
+//     the GPU is full of coherent waves, the seventh wave is worth more (5 %).
+bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
+{
+    const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
+    const bool latency_launch = frames_in_launch == 1 && spp == 1;
+    return divergent_scene || latency_launch;
+}
+
 // The stack kernel reads its FrameViews from device memory (far fewer scalar registers held, and
 // spilled, than with the 480-byte view as a by-value kernel argument): `count` views travel through a
 // ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
@@ -407,7 +423,8 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         plain_view = plain_view && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
     const hipError_t e = (scene->kernel_id == 2 && plain_view)
         ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
-        : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels);
+        : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
+                             leaf_stage_policy(scene, count, views[0].spp), d_out, frame_stride, stream, scene->stack_levels);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));

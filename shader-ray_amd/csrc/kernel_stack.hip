@@ -6,6 +6,7 @@
 // workgroups (32 waves) per CU.
 #include "launch.h"
 #include "stack_traversal.h"
+#include "uniform_driver.h"
 
 namespace shray {
 
@@ -23,6 +24,11 @@ bool g_diag_plain_kernel = false;
 #ifndef SHRAY_MIN_WAVES
 #define SHRAY_MIN_WAVES 7
 #endif
+// the instances whose leaf stage deals triangles to idle lanes (wave_traversal.h) hold a second ray's worth of
+// values while they do: six waves per SIMD (<= 80 registers) keeps the spills out of the loops
+#ifndef SHRAY_MIN_WAVES_DEALT
+#define SHRAY_MIN_WAVES_DEALT 6
+#endif
 // the instances with the diffuse / shadow-ray branch carry more state: one wave fewer
 #ifndef SHRAY_MIN_WAVES_GENERAL
 #define SHRAY_MIN_WAVES_GENERAL 5
@@ -35,54 +41,105 @@ bool g_diag_plain_kernel = false;
 #define SHRAY_LDS_PAD 0
 #endif
 
-template <bool COUNT, bool DIFF, bool ONE_SAMPLE = false, bool METAL = false>
-__global__ void __launch_bounds__(kBlock, METAL ? SHRAY_MIN_WAVES : SHRAY_MIN_WAVES_GENERAL) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters)
-{
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock> trav;
-    trav.stack = lds_stack + threadIdx.x;
-    trace_pixels<StackTraversal<kBlock>, COUNT, DIFF, ONE_SAMPLE, METAL>(sc, fr, out, counters, trav);
-}
-
-// spp == 1 and a zero diffuse colour: the instances without a sample loop / without the diffuse branch
+// Two drivers share the traversal.  Plain frames (which == 0, every timed launch) run trace() in its
+// convergent form (uniform_driver.h), where all 64 lanes enter each traversal together and the dealt leaf
+// stage can use the idle ones; the shader's debug views (which = 1, 2, 3, 5) and the patch-order experiment
+// keep the per-lane driver of trace_common.h.
 static bool one_sample(const FrameView &fr) { return fr.spp == 1; }
 static bool metal(const FrameView &fr)
 {
     return !(fr.diffuse_color[0] > 0.0f && fr.diffuse_color[1] > 0.0f && fr.diffuse_color[2] > 0.0f);
 }
+static bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
 
-// Batch form: workgroup (x, y) renders patch x of frame y.  Workgroups are dispatched x-fastest, so
-// frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
-template <bool DIFF, bool ONE_SAMPLE, bool METAL>
-__global__ void __launch_bounds__(kBlock, METAL ? SHRAY_MIN_WAVES : SHRAY_MIN_WAVES_GENERAL) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
-                                                                                   float4 *out, size_t frame_stride)
+template <bool DEAL>
+__device__ __forceinline__ StackTraversal<kBlock, DEAL> make_traversal(uint32_t *lds, int stack_levels)
 {
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock> trav;
-    trav.stack = lds_stack + threadIdx.x;
-    trace_pixels<StackTraversal<kBlock>, false, DIFF, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
-                                                                         nullptr, trav);
+    StackTraversal<kBlock, DEAL> trav;
+    trav.stack = lds + threadIdx.x;
+    trav.ids = lds + (size_t)stack_levels * kBlock + (threadIdx.x & ~63u);
+    return trav;
 }
 
-// `all_metal`: every frame of the batch has a zero diffuse colour
+constexpr int min_waves(bool metal, bool deal)
+{
+    return metal ? (deal ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES) : SHRAY_MIN_WAVES_GENERAL;
+}
+
+// spp == 1 and a zero diffuse colour get instances without the sample loop / the diffuse branch
+template <bool COUNT, bool ONE_SAMPLE, bool METAL>
+__global__ void __launch_bounds__(kBlock, min_waves(METAL, true)) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
+                                                                                    int stack_levels)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock, true> trav = make_traversal<true>(lds_stack, stack_levels);
+    trace_pixels_uniform<StackTraversal<kBlock, true>, COUNT, ONE_SAMPLE, METAL>(sc, fr, out, counters, trav);
+}
+
+template <bool COUNT, bool DIFF>
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
+                                                                                          int stack_levels)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels);
+    trace_pixels<StackTraversal<kBlock, false>, COUNT, DIFF>(sc, fr, out, counters, trav);
+}
+
+// Batch forms: workgroup (x, y) renders patch x of frame y.  Workgroups are dispatched x-fastest, so
+// frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
+// DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
+template <bool ONE_SAMPLE, bool METAL, bool DEAL>
+__global__ void __launch_bounds__(kBlock, min_waves(METAL, DEAL)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+                                                                                          float4 *out, size_t frame_stride, int stack_levels)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock, DEAL> trav = make_traversal<DEAL>(lds_stack, stack_levels);
+    trace_pixels_uniform<StackTraversal<kBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
+                                                                                nullptr, trav);
+}
+
+template <bool DIFF>
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+                                                                                                float4 *out, size_t frame_stride, int stack_levels)
+{
+    extern __shared__ uint32_t lds_stack[];
+    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels);
+    trace_pixels<StackTraversal<kBlock, false>, false, DIFF>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
+}
+
+static size_t stack_lds_bytes(int stack_levels)
+{
+    // stack columns + the dealt leaf stage's id tables (64 dwords per wave)
+    return ((size_t)kBlock * (size_t)stack_levels + kBlock) * sizeof(uint32_t) + SHRAY_LDS_PAD;
+}
+
+// `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;
+// `deal`: the gold-class instances use the dealt leaf stage (six waves per SIMD) instead of the plain one (seven)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
-                              float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
+                              bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
 {
     const dim3 grid(first.total_patches, (unsigned)count), block(kBlock);
-    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + SHRAY_LDS_PAD;
+    const size_t lds_bytes = stack_lds_bytes(stack_levels);
     const bool one = SHRAY_SPECIALIZE && one_sample(first), metallic = SHRAY_SPECIALIZE && all_metal;
-#define SHRAY_LAUNCH_BATCH(D, O, M) \
-    hipLaunchKernelGGL((trace_stack_batch_kernel<D, O, M>), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride)
-    if (first.which == 1 || first.which == 2)
-        SHRAY_LAUNCH_BATCH(true, false, false);
+#define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
+    if (!all_plain && (first.which == 1 || first.which == 2))
+        SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<true>);
+    else if (!all_plain)
+        SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<false>);
+    // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of the gold-class instances; the
+    // instances with the diffuse branch run at five waves per SIMD either way and always deal
+    else if (one && metallic && deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, true>));
     else if (one && metallic)
-        SHRAY_LAUNCH_BATCH(false, true, true);
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, false>));
     else if (one)
-        SHRAY_LAUNCH_BATCH(false, true, false);
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, false, true>));
+    else if (metallic && deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<false, true, true>));
     else if (metallic)
-        SHRAY_LAUNCH_BATCH(false, false, true);
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<false, true, false>));
     else
-        SHRAY_LAUNCH_BATCH(false, false, false);
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<false, false, true>));
 #undef SHRAY_LAUNCH_BATCH
     return hipGetLastError();
 }
@@ -91,28 +148,34 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
                         hipStream_t stream, int stack_levels)
 {
     const dim3 grid(fr.total_patches), block(kBlock);
-    const size_t lds_bytes = (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + SHRAY_LDS_PAD;
-#ifdef SHRAY_DIAGNOSTICS
-    if (counters && g_diag_plain_kernel) {
-        hipLaunchKernelGGL((trace_stack_kernel<false, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
-        return hipGetLastError();
-    }
-#endif
+    const size_t lds_bytes = stack_lds_bytes(stack_levels);
+#define SHRAY_LAUNCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, fr, out, counters, stack_levels)
     const bool diff = fr.which == 1 || fr.which == 2;   // only those views need the ray differentials carried along
-    if (counters && diff)
-        hipLaunchKernelGGL((trace_stack_kernel<true, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+    if (!plain_view(fr) || fr.patch_order) {
+        if (counters && diff)
+            SHRAY_LAUNCH((trace_stack_view_kernel<true, true>));
+        else if (counters)
+            SHRAY_LAUNCH((trace_stack_view_kernel<true, false>));
+        else if (diff)
+            SHRAY_LAUNCH((trace_stack_view_kernel<false, true>));
+        else
+            SHRAY_LAUNCH((trace_stack_view_kernel<false, false>));
+    }
+#ifdef SHRAY_DIAGNOSTICS
+    else if (counters && g_diag_plain_kernel)
+        SHRAY_LAUNCH((trace_stack_kernel<false, false, false>));
+#endif
     else if (counters)
-        hipLaunchKernelGGL((trace_stack_kernel<true, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
-    else if (diff)
-        hipLaunchKernelGGL((trace_stack_kernel<false, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+        SHRAY_LAUNCH((trace_stack_kernel<true, false, false>));
     else if (SHRAY_SPECIALIZE && one_sample(fr) && metal(fr))
-        hipLaunchKernelGGL((trace_stack_kernel<false, false, true, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+        SHRAY_LAUNCH((trace_stack_kernel<false, true, true>));
     else if (SHRAY_SPECIALIZE && one_sample(fr))
-        hipLaunchKernelGGL((trace_stack_kernel<false, false, true, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+        SHRAY_LAUNCH((trace_stack_kernel<false, true, false>));
     else if (SHRAY_SPECIALIZE && metal(fr))
-        hipLaunchKernelGGL((trace_stack_kernel<false, false, false, true>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+        SHRAY_LAUNCH((trace_stack_kernel<false, false, true>));
     else
-        hipLaunchKernelGGL((trace_stack_kernel<false, false>), grid, block, lds_bytes, stream, sc, fr, out, counters);
+        SHRAY_LAUNCH((trace_stack_kernel<false, false, false>));
+#undef SHRAY_LAUNCH
     return hipGetLastError();
 }
 

@@ -34,6 +34,11 @@ namespace shray {
 #define SHRAY_KEEP_WALKING 28
 #endif
 constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
+// with the dealt leaf stage a leaf stage with few parked lanes is cheap, so the node loop may yield earlier
+#ifndef SHRAY_KEEP_WALKING_DEALT
+#define SHRAY_KEEP_WALKING_DEALT 48
+#endif
+constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #ifndef SHRAY_RELATIVE_KEEP
 #define SHRAY_RELATIVE_KEEP 1
 #endif
@@ -46,12 +51,32 @@ constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
 #endif
 constexpr int kStackMinParked = SHRAY_MIN_PARKED;
 
-template <int BLOCK>
+// DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
+template <int BLOCK, bool DEAL = true>
 struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
+    uint32_t *ids;     // LDS, 64 dwords per wave: scratch of the dealt leaf stage (wave_traversal.h)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+
+    // Convergent form (uniform_driver.h): all 64 lanes of the wave call it together; has_ray = this lane's pixel
+    // has a ray to trace.  Lanes without one take part in the dealt leaf stage as workers.  Returns the number
+    // of rays the wave traced.
+    template <bool COUNT>
+    __device__ __forceinline__ int closest(const SceneView &sc, const FrameView &fr, bool has_ray, V3 P, V3 D, Hit &hit,
+                                           RayCounters &rc)
+    {
+        const int traced = __popcll(wave_ballot(has_ray));
+        if (!traced)
+            return 0;
+        LaneTraversal t;
+        lane_begin<COUNT>(sc, t, P, D, rc, has_ray);
+        int state = has_ray ? LT_WALK : LT_ENDED;
+        run<COUNT, true>(sc, fr, t, state, rc);
+        hit = t.hit;
+        return traced;
+    }
 
     template <bool COUNT>
     __device__ __forceinline__ void closest(const SceneView &sc, const FrameView &fr, V3 P, V3 D, Hit &hit,
@@ -60,6 +85,14 @@ struct StackTraversal {
         LaneTraversal t;
         lane_begin<COUNT>(sc, t, P, D, rc);
         int state = LT_WALK;
+        run<COUNT, false>(sc, fr, t, state, rc);
+        hit = t.hit;
+    }
+
+    // CONVERGED: every lane of the wave is executing (the dealt leaf stage may use them all)
+    template <bool COUNT, bool CONVERGED>
+    __device__ __forceinline__ void run(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state, RayCounters &rc)
+    {
 #if SHRAY_UNIFIED_WALK
 #ifdef SHRAY_DIAGNOSTICS
         const unsigned long long c0 = __builtin_amdgcn_s_memtime();
@@ -76,7 +109,7 @@ struct StackTraversal {
 #if SHRAY_RELATIVE_KEEP
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
-            const int keep = max(SHRAY_KEEP_FLOOR, (alive * kStackKeepWalking + 32) >> 6);
+            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
             inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
 #else
             inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
@@ -84,7 +117,10 @@ struct StackTraversal {
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
-            leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
+            if (SHRAY_DEAL_LEAVES && DEAL && CONVERGED)
+                leaf_stage_dealt<COUNT, BLOCK>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
+            else
+                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c2 = __builtin_amdgcn_s_memtime();
             diag_tally[2] += c1 - c0;
@@ -92,7 +128,6 @@ struct StackTraversal {
 #endif
         } while (wave_ballot(state != LT_ENDED));
 #endif
-        hit = t.hit;
     }
 };
 

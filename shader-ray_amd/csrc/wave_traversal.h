@@ -170,6 +170,63 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
 }
 
+// The same visit with its bookkeeping written as predicates and selects: every side effect (push, pop, link,
+// iteration cap, parking) appears once, under its own condition, instead of once per control-flow path --
+// the paths above are merged by the compiler with a register copy per live value and path (20 v_mov per visit).
+#ifndef SHRAY_LEAN_VISIT
+#define SHRAY_LEAN_VISIT 0
+#endif
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ int lane_visit_lean(const FrameView &fr, LaneTraversal &t, uint32_t *stack, RayCounters &rc,
+                                               const float4 lo, const float4 hi)
+{
+    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
+    const bool leaf = (int32_t)b < 0;
+    if (COUNT) {
+        rc.node_visits++;
+        rc.leaf_visits += leaf ? 1u : 0u;   // the reference fetches (start, count) before the box test, fs:263-267
+    }
+    // range_intersect_box against [0, 1e8] (fs:200-217), as in lane_visit_loaded
+    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
+    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
+                     div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
+    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
+                     div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
+    if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
+        r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
+        r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
+    }
+    const bool entered = !(r0 >= r1) && (r0 < t.hit.t);
+    const uint32_t count = min(b & ~kLeafFlag, (uint32_t)fr.max_leaf_tests);
+    const bool park = entered && leaf && count > 0;      // the lane tests this leaf's triangles next
+    const bool descend = entered && !leaf;
+    const bool pop = !park && !descend;                   // missed, or an empty leaf: the next pending subtree
+    // branch: near child first, far child pending (packed_layout.h)
+    const uint32_t pos_child = a & kChildMask, neg_child = b;
+    const bool neg_first = (t.positive_dir >> (a >> 30)) & 1u;
+    const uint32_t near_child = neg_first ? neg_child : pos_child, far_child = neg_first ? pos_child : neg_child;
+    if (descend)
+        stack[t.sp * BLOCK] = far_child;
+    const bool take = pop && t.sp != 0;
+    uint32_t next = near_child;
+    if (take)
+        next = stack[(t.sp - 1) * BLOCK];
+    t.sp += descend ? 1 : (take ? -1 : 0);
+    t.node = park ? t.node : next;
+    t.leaf_first = park ? a : t.leaf_first;
+    t.leaf_count = park ? count : t.leaf_count;
+    t.leaf_r0 = park ? r0 : t.leaf_r0;
+    t.leaf_r1 = park ? r1 : t.leaf_r1;
+    t.leaf_j = 0;
+    // the visit is over unless the lane parked (then lane_advance runs after its triangles): link followed, cap applied
+    const bool finished = pop && !take;
+    const bool capped = !park && !finished && t.iter == fr.max_bvh_iterations - 1;   // set_bad_hit, fs:436-438
+    t.hit.t = capped ? -1.0f : t.hit.t;
+    t.iter += park ? 0 : 1;
+    return park ? LT_LEAF : ((finished || capped) ? LT_ENDED : LT_WALK);
+}
+
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack,
                                           RayCounters &rc)
@@ -277,7 +334,11 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                 const float4 lo = nodes[2u * t.node];
                 const float4 hi = nodes[2u * t.node + 1u];
                 SHRAY_DIAG_WAIT(4);
+#if SHRAY_LEAN_VISIT
+                state = lane_visit_lean<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+#else
                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+#endif
             }
         }
         const int walking = __popcll(wave_ballot(state == LT_WALK));
@@ -350,6 +411,137 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
     }
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dealt leaf stage.  The plain stage above takes max(count) turns whoever is parked: one lane sitting in a
+// 10-triangle leaf costs ten dependent fetch-and-test rounds with one lane active (the normal case in
+// divergent waves: on the 1M-triangle scene the leaf loop runs at 24 % of its lanes, oracle/tools/wave_sim.py).
+// Here the wave's idle lanes do the work: with K <= 32 lanes parked, each parked ray gets a group of
+// G = 2, 4, 8 or 16 worker lanes (G * K <= 64); worker i of a group pulls the ray (ds_bpermute) and tests
+// triangles i, i + G, ... of its leaf, so the stage takes ceil(count / G) rounds -- one memory round trip
+// instead of up to ten when few lanes are parked.
+//
+// Exactness: triangle_intersect's outcome for one triangle depends on hit.t only through the early-out
+// `d > hit.t` (fs:327); every other test is a pure function of (ray, triangle, leaf range).  Testing the
+// leaf's triangles in order therefore ends with: among the candidates that pass those tests and have
+// d <= the hit.t the leaf started with, the smallest d, and of equal d the LAST in order (equal d
+// overwrites, the test is `>`).  Each worker keeps that rule over its own increasing j, the group combines
+// by (smaller d, then larger j), the parked lane applies the winner.  Same arithmetic on the same values:
+// bit-identical hits; the counting twin tallies the same triangle tests (in the worker lanes).
+#ifndef SHRAY_DEAL_LEAVES
+#define SHRAY_DEAL_LEAVES 1
+#endif
+#ifndef SHRAY_DEAL_MAX_PARKED
+#define SHRAY_DEAL_MAX_PARKED 32   // at most 32: a group is at least two lanes
+#endif
+
+__device__ __forceinline__ float lane_pull(int src_lane, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int lane_pull(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// lane_triangle_candidate for a ray held in plain values (the worker's copy of another lane's ray)
+__device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r1, const float4 q0, const float4 q1,
+                                                   const float4 q2, float &dist, float &u, float &w)
+{
+    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
+    const V3 M = cross3(e1, D);
+    const float det = dot3(e0, M);
+    const float inv_det = 1.0f / det;
+    const V3 T = P - v0;
+    const V3 Q = cross3(T, e0);
+    dist = -dot3(e1, Q) * inv_det;
+    u = dot3(T, M) * inv_det;
+    w = dot3(D, Q) * inv_det;
+    if (det > -0.0000001f && det < 0.0000001f)
+        return false;
+    if (dist < r0 || dist > r1)
+        return false;
+    if (u < 0.0f || u > 1.0f)
+        return false;
+    if (w < 0.0f || u + w > 1.0f)
+        return false;
+    return true;
+}
+
+// `ids`: 64 dwords of LDS owned by this wave (rank of a parked lane -> its lane number)
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                                 uint32_t *stack, RayCounters &rc, uint32_t *ids SHRAY_DIAG_PARAM)
+{
+    const unsigned long long parked = wave_ballot(state == LT_LEAF);
+    if (!parked)
+        return;
+    const int K = __popcll(parked);
+    if (K > SHRAY_DEAL_MAX_PARKED) {
+        leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG_FWD);
+        return;
+    }
+    const int log_g = K <= 4 ? 4 : (K <= 8 ? 3 : (K <= 16 ? 2 : 1));   // G = 16, 8, 4, 2
+    const int G = 1 << log_g;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
+    if (state == LT_LEAF)
+        ids[rank] = (uint32_t)lane;
+    const int group = lane >> log_g, sub = lane & (G - 1);
+    const bool worker = group < K;
+    const int src = worker ? (int)ids[group] : lane;    // same wave, LDS operations complete in order
+    // the parked ray, as its workers see it
+    const V3 P = mk(lane_pull(src, t.P.x), lane_pull(src, t.P.y), lane_pull(src, t.P.z));
+    const V3 D = mk(lane_pull(src, t.D.x), lane_pull(src, t.D.y), lane_pull(src, t.D.z));
+    const float r0 = lane_pull(src, t.leaf_r0), r1 = lane_pull(src, t.leaf_r1);
+    // worker i of a group walks triangles first + i, first + i + G, ... < end; the winner is kept as the triangle's index
+    const uint32_t first = (uint32_t)lane_pull(src, (int)t.leaf_first);
+    // (every pull is a statement of its own, executed by all 64 lanes: ds_bpermute returns 0 for a source lane that
+    // is masked off, so a pull must never sit inside a conditional expression)
+    const uint32_t count = (uint32_t)lane_pull(src, (int)t.leaf_count);
+    const uint32_t end = worker ? first + count : 0u;
+    float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
+    uint32_t best = 0xffffffffu;    // no candidate accepted
+    SHRAY_DIAG_COUNT(6);
+    for (uint32_t tri = first + (uint32_t)sub; wave_ballot(tri < end); tri += (uint32_t)G) {
+        SHRAY_DIAG_COUNT(1);
+        if (tri < end) {
+            float4 q0, q1, q2;
+            load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * tri, q0, q1, q2);
+            if (COUNT)
+                rc.triangle_tests++;
+            float d, u, w;
+            if (triangle_candidate(P, D, r0, r1, q0, q1, q2, d, u, w) && !(d > best_d)) {
+                best_d = d;
+                best_u = u;
+                best_w = w;
+                best = tri;
+            }
+        }
+    }
+    // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
+    for (int step = 1; step < G; step <<= 1) {
+        const int other = lane ^ step;
+        const float od = lane_pull(other, best_d);
+        const uint32_t ob = (uint32_t)lane_pull(other, (int)best);
+        const bool take = ob != 0xffffffffu && (best == 0xffffffffu || od < best_d || (od == best_d && ob > best));
+        const float ou = lane_pull(other, best_u), ow = lane_pull(other, best_w);
+        best_d = take ? od : best_d;
+        best_u = take ? ou : best_u;
+        best_w = take ? ow : best_w;
+        best = take ? ob : best;
+    }
+    // the parked lane collects its group's winner and moves on (fs:416-433)
+    const int from = rank << log_g;
+    const float wd = lane_pull(from, best_d), wu = lane_pull(from, best_u), ww = lane_pull(from, best_w);
+    const uint32_t won = (uint32_t)lane_pull(from, (int)best);
+    if (state == LT_LEAF) {
+        if (won != 0xffffffffu) {
+            t.hit.which = (float)won;
+            t.hit.t = wd;
+            t.hit.bu = wu;
+            t.hit.bv = ww;
+        }
+        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+    }
 }
 
 // One unified step: each walking lane visits ONE node and -- when at least `min_parked` lanes

@@ -170,6 +170,42 @@ int shray_set_device(int device_index);
 /* Fills struct_size, identity matrices and the shader-constant defaults. */
 void shray_frame_params_init(shray_frame_params *params);
 
+/* GPU-side flattener ------------------------------------------------------ */
+/*
+ * get_shader_data (world.cpp:298-347) on the GPU: the host-built BVH goes in as plain arrays, nodes in
+ * PRE-order (a node, then its negative subtree, then its positive subtree; root = node 0), and the
+ * scene_shader_data arrays come out in device memory, bit-identical to the host flattener's: triangle
+ * corners expanded to float3 arrays (world.cpp:303-318), nodes numbered in-order with their boxes, split
+ * directions, children and leaf ranges (store_group_data, world.cpp:179-210), and the eight threaded
+ * (hit, miss) tables (create_hitmiss, world.cpp:231-288) -- every node finds its own links by walking up
+ * its ancestors, so all nodes and all eight direction codes are threaded in parallel.
+ * libshray_host's shray_host_export_tree() fills the description from a loaded world.
+ */
+typedef struct shray_tree_desc {
+    uint32_t struct_size;            /* sizeof(shray_tree_desc) */
+    int32_t node_count;
+    const int32_t *node_parent;      /* -1 for the root */
+    const int32_t *node_negative;    /* child indices, -1 for a leaf (group.h:29-30) */
+    const int32_t *node_positive;
+    const float *node_box;           /* 6 floats per node: boxmin.xyz, boxmax.xyz */
+    const float *node_direction;     /* 3 floats per node: the split direction D (group.h:24) */
+    const int32_t *node_start;       /* leaves: first triangle and triangle count (group.h:35-36) */
+    const int32_t *node_triangles;
+    int32_t triangle_count;
+    const int32_t *triangle_vertices; /* 3 vertex indices per triangle, in post-build order */
+    int32_t vertex_count;
+    const float *vertex_data;        /* 9 floats per vertex: position, colour, normal (geometry.h:34-38) */
+} shray_tree_desc;
+
+typedef struct shray_device_flat shray_device_flat;   /* the flattened arrays, resident on the device */
+
+int shray_flatten_device(const shray_tree_desc *tree, uint32_t data_texture_width, shray_device_flat **out_flat);
+/* *desc gets the counts and DEVICE pointers of the arrays (valid until the object is destroyed). */
+int shray_device_flat_describe(const shray_device_flat *flat, shray_scene_desc *desc);
+/* Copies the arrays to host memory owned by the object; *desc gets the counts and HOST pointers. */
+int shray_device_flat_download(shray_device_flat *flat, shray_scene_desc *desc);
+int shray_device_flat_destroy(shray_device_flat *flat);
+
 /* Scene ------------------------------------------------------------------ */
 int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene);
 int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height);

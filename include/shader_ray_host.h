@@ -54,6 +54,10 @@ int shray_host_get_world_info(const shray_host_world *world, shray_host_world_in
  * `world` and valid until it is freed or flattened again. */
 int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width, shray_scene_desc *desc);
 
+/* The BVH as plain pre-order arrays (shray_tree_desc, shader_ray_hip.h) for the GPU-side flattener
+ * shray_flatten_device.  The arrays stay owned by `world` until it is freed or exported again. */
+int shray_host_export_tree(shray_host_world *world, shray_tree_desc *tree);
+
 /* Start-up view (ray.cpp:1077-1088) and the per-frame block (ray.cpp:648-704). */
 int shray_host_default_view(const shray_host_world *world, shray_host_view *view);
 int shray_host_frame_params(shray_host_world *world, const shray_host_view *view, int width, int height,

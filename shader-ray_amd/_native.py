@@ -60,6 +60,18 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class TreeDesc(C.Structure):
+    """shray_tree_desc (include/shader_ray_hip.h): the BVH as pre-order arrays, input of the GPU flattener."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("node_count", C.c_int32),
+        ("node_parent", C.POINTER(C.c_int32)), ("node_negative", C.POINTER(C.c_int32)), ("node_positive", C.POINTER(C.c_int32)),
+        ("node_box", C.POINTER(C.c_float)), ("node_direction", C.POINTER(C.c_float)),
+        ("node_start", C.POINTER(C.c_int32)), ("node_triangles", C.POINTER(C.c_int32)),
+        ("triangle_count", C.c_int32), ("triangle_vertices", C.POINTER(C.c_int32)),
+        ("vertex_count", C.c_int32), ("vertex_data", C.POINTER(C.c_float)),
+    ]
+
+
 class HostView(C.Structure):
     _fields_ = [
         ("fov", C.c_float), ("zoom", C.c_float), ("object_rotation", C.c_float * 4),
@@ -92,6 +104,10 @@ HIP_SYMBOLS = [
     ("shray_render_host_async", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("shray_pinned_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("shray_pinned_free", C.c_int, [C.c_void_p]),
+    ("shray_flatten_device", C.c_int, [C.POINTER(TreeDesc), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("shray_device_flat_describe", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    ("shray_device_flat_download", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    ("shray_device_flat_destroy", C.c_int, [C.c_void_p]),
     ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
     ("shray_render_batch_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -109,6 +125,7 @@ HOST_SYMBOLS = [
     ("shray_host_free_world", None, [C.c_void_p]),
     ("shray_host_get_world_info", C.c_int, [C.c_void_p, C.POINTER(HostWorldInfo)]),
     ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
+    ("shray_host_export_tree", C.c_int, [C.c_void_p, C.POINTER(TreeDesc)]),
     ("shray_host_default_view", C.c_int, [C.c_void_p, C.POINTER(HostView)]),
     ("shray_host_frame_params", C.c_int, [C.c_void_p, C.POINTER(HostView), C.c_int, C.c_int, C.POINTER(FrameParams)]),
     ("shray_host_trackball_motion", C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]),

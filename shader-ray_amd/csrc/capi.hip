@@ -272,12 +272,31 @@ struct TreeBuilder {
         std::vector<uint32_t> new_index(n, 0);
         std::vector<uint32_t> order;
         order.reserve(n);
+        std::vector<char> numbered(n, 0);
+#if defined(SHRAY_LDS_TOP) && SHRAY_LDS_TOP > 0
+        // experiment (kernel_stack.hip under the same flag): the top of the tree first, breadth first
+        {
+            std::vector<uint32_t> level(1, (uint32_t)d.tree_root);
+            for (size_t k = 0; k < level.size() && order.size() < (size_t)SHRAY_LDS_TOP; k++) {
+                const uint32_t g = level[k];
+                new_index[g] = (uint32_t)order.size();
+                order.push_back(g);
+                numbered[g] = 1;
+                if (neg[g] >= 0) {
+                    level.push_back((uint32_t)neg[g]);
+                    level.push_back((uint32_t)pos[g]);
+                }
+            }
+        }
+#endif
         std::vector<uint32_t> todo(1, (uint32_t)d.tree_root);
         while (!todo.empty()) {
             const uint32_t g = todo.back();
             todo.pop_back();
-            new_index[g] = (uint32_t)order.size();
-            order.push_back(g);
+            if (!numbered[g]) {
+                new_index[g] = (uint32_t)order.size();
+                order.push_back(g);
+            }
             if (neg[g] >= 0) {
                 todo.push_back((uint32_t)pos[g]);
                 todo.push_back((uint32_t)neg[g]);
@@ -454,6 +473,9 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
 }
 
 }   // namespace
+
+// error reporting for the library's other translation units (flatten.hip)
+extern "C" int shrayi_fail(int code, const char *message) { return fail(code, "%s", message); }
 
 extern "C" {
 

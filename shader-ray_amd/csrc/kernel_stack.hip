@@ -53,11 +53,21 @@ static bool metal(const FrameView &fr)
 static bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
 
 template <bool DEAL>
-__device__ __forceinline__ StackTraversal<kBlock, DEAL> make_traversal(uint32_t *lds, int stack_levels)
+__device__ __forceinline__ StackTraversal<kBlock, DEAL> make_traversal(uint32_t *lds, int stack_levels, const SceneView &sc)
 {
     StackTraversal<kBlock, DEAL> trav;
     trav.stack = lds + threadIdx.x;
     trav.ids = lds + (size_t)stack_levels * kBlock + (threadIdx.x & ~63u);
+#if SHRAY_LDS_TOP
+    // experiment: the workgroup stages the top of the tree (the first SHRAY_LDS_TOP nodes, numbered breadth first
+    // by capi.hip under the same flag) behind the stack columns and the id tables
+    float4 *top = reinterpret_cast<float4 *>(lds + (size_t)stack_levels * kBlock + kBlock);
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
+    for (unsigned int k = threadIdx.x; k < 2u * SHRAY_LDS_TOP && k < 2u * sc.group_count; k += kBlock)
+        top[k] = nodes[k];
+    __syncthreads();
+    trav.top = top;
+#endif
     return trav;
 }
 
@@ -71,8 +81,8 @@ template <bool COUNT, bool ONE_SAMPLE, bool METAL>
 __global__ void __launch_bounds__(kBlock, min_waves(METAL, true)) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
                                                                                     int stack_levels)
 {
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock, true> trav = make_traversal<true>(lds_stack, stack_levels);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    StackTraversal<kBlock, true> trav = make_traversal<true>(lds_stack, stack_levels, sc);
     trace_pixels_uniform<StackTraversal<kBlock, true>, COUNT, ONE_SAMPLE, METAL>(sc, fr, out, counters, trav);
 }
 
@@ -80,8 +90,8 @@ template <bool COUNT, bool DIFF>
 __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
                                                                                           int stack_levels)
 {
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels, sc);
     trace_pixels<StackTraversal<kBlock, false>, COUNT, DIFF>(sc, fr, out, counters, trav);
 }
 
@@ -92,8 +102,8 @@ template <bool ONE_SAMPLE, bool METAL, bool DEAL>
 __global__ void __launch_bounds__(kBlock, min_waves(METAL, DEAL)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
                                                                                           float4 *out, size_t frame_stride, int stack_levels)
 {
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock, DEAL> trav = make_traversal<DEAL>(lds_stack, stack_levels);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    StackTraversal<kBlock, DEAL> trav = make_traversal<DEAL>(lds_stack, stack_levels, sc);
     trace_pixels_uniform<StackTraversal<kBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
                                                                                 nullptr, trav);
 }
@@ -102,15 +112,15 @@ template <bool DIFF>
 __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
                                                                                                 float4 *out, size_t frame_stride, int stack_levels)
 {
-    extern __shared__ uint32_t lds_stack[];
-    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    StackTraversal<kBlock, false> trav = make_traversal<false>(lds_stack, stack_levels, sc);
     trace_pixels<StackTraversal<kBlock, false>, false, DIFF>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
 }
 
 static size_t stack_lds_bytes(int stack_levels)
 {
     // stack columns + the dealt leaf stage's id tables (64 dwords per wave)
-    return ((size_t)kBlock * (size_t)stack_levels + kBlock) * sizeof(uint32_t) + SHRAY_LDS_PAD;
+    return ((size_t)kBlock * (size_t)stack_levels + kBlock) * sizeof(uint32_t) + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
 }
 
 // `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;

@@ -56,6 +56,7 @@ template <int BLOCK, bool DEAL = true>
 struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
     uint32_t *ids;     // LDS, 64 dwords per wave: scratch of the dealt leaf stage (wave_traversal.h)
+    const float4 *top = nullptr;   // LDS copy of the first SHRAY_LDS_TOP packed nodes (experiment, else unused)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -110,7 +111,7 @@ struct StackTraversal {
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
             const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
-            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
+            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG, top);
 #else
             inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
 #endif

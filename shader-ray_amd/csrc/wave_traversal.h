@@ -39,6 +39,10 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 #endif
 
 // node visits per lane between two evaluations of inner_stage's exit tests (same trade as above)
+// experiment: stage the first SHRAY_LDS_TOP packed nodes in LDS (0 = off, the shipped form)
+#ifndef SHRAY_LDS_TOP
+#define SHRAY_LDS_TOP 0
+#endif
 #ifndef SHRAY_NODE_TURNS
 #define SHRAY_NODE_TURNS 2
 #endif
@@ -320,7 +324,8 @@ __device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTrav
 // them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM)
+                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM,
+                                            const float4 *lds_top = nullptr)
 {
     for (;;) {
         if (!wave_ballot(state == LT_WALK))
@@ -331,8 +336,21 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
             if (state == LT_WALK) {
                 const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
                 SHRAY_DIAG_T0
+#if SHRAY_LDS_TOP
+                // experiment (profiles/r02/lds_top_ab.txt): the first SHRAY_LDS_TOP nodes (the top levels, breadth
+                // first) are read from a copy the workgroup staged in LDS
+                float4 lo, hi;
+                if (t.node < (uint32_t)SHRAY_LDS_TOP) {
+                    lo = lds_top[2u * t.node];
+                    hi = lds_top[2u * t.node + 1u];
+                } else {
+                    lo = nodes[2u * t.node];
+                    hi = nodes[2u * t.node + 1u];
+                }
+#else
                 const float4 lo = nodes[2u * t.node];
                 const float4 hi = nodes[2u * t.node + 1u];
+#endif
                 SHRAY_DIAG_WAIT(4);
 #if SHRAY_LEAN_VISIT
                 state = lane_visit_lean<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);

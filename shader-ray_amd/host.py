@@ -54,29 +54,21 @@ class World:
         self._desc = desc
         return desc
 
+    def export_tree(self) -> N.TreeDesc:
+        """The BVH as pre-order arrays (shray_host_export_tree): input of the GPU flattener.  The arrays
+        are owned by this World."""
+        tree = N.TreeDesc()
+        if self._lib.shray_host_export_tree(self._handle, C.byref(tree)) != 0:
+            raise RuntimeError("shray_host_export_tree failed")
+        tree._owner = self
+        return tree
+
     def arrays(self, data_texture_width: int = 2048) -> dict:
         """The flattened arrays as numpy copies (populated prefix only), keyed like
         scene_shader_data (reference world.h:68-93)."""
         d = self._desc if self._desc is not None else self.flatten(data_texture_width)
-        nv, ng = d.vertex_count, d.group_count
-        stride = d.data_texture_width * d.group_data_rows
+        return desc_arrays(d)
 
-        def take(ptr, n):
-            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.float32)
-
-        out = {
-            "vertex_count": nv, "vertex_data_rows": d.vertex_data_rows, "group_count": ng,
-            "group_data_rows": d.group_data_rows, "tree_root": d.tree_root,
-            "vertex_positions": take(d.vertex_positions, 3 * nv), "vertex_normals": take(d.vertex_normals, 3 * nv),
-            "vertex_colors": take(d.vertex_colors, 3 * nv),
-            "group_boxmin": take(d.group_boxmin, 3 * ng), "group_boxmax": take(d.group_boxmax, 3 * ng),
-            "group_directions": take(d.group_directions, 3 * ng), "group_children": take(d.group_children, 2 * ng),
-            "group_objects": take(d.group_objects, 2 * ng),
-        }
-        hm = np.ctypeslib.as_array(d.group_hitmiss, shape=(8, stride, 2)) if stride else np.zeros((8, 0, 2), np.float32)
-        for code in range(8):
-            out[f"group_hitmiss_{code}"] = hm[code, :ng].reshape(-1).copy()
-        return out
 
     def default_view(self) -> N.HostView:
         view = N.HostView()
@@ -97,6 +89,29 @@ class World:
         if self._lib.shray_host_frame_params(self._handle, C.byref(view), width, height, C.byref(params)) != 0:
             raise RuntimeError("frame parameter computation failed")
         return params
+
+
+def desc_arrays(d) -> dict:
+    """numpy copies of the arrays a SceneDesc with HOST pointers names (populated prefix only)."""
+    nv, ng = d.vertex_count, d.group_count
+    stride = d.data_texture_width * d.group_data_rows
+
+    def take(ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+
+    out = {
+        "vertex_count": nv, "vertex_data_rows": d.vertex_data_rows, "group_count": ng,
+        "group_data_rows": d.group_data_rows, "tree_root": d.tree_root,
+        "vertex_positions": take(d.vertex_positions, 3 * nv), "vertex_normals": take(d.vertex_normals, 3 * nv),
+        "vertex_colors": take(d.vertex_colors, 3 * nv),
+        "group_boxmin": take(d.group_boxmin, 3 * ng), "group_boxmax": take(d.group_boxmax, 3 * ng),
+        "group_directions": take(d.group_directions, 3 * ng), "group_children": take(d.group_children, 2 * ng),
+        "group_objects": take(d.group_objects, 2 * ng),
+    }
+    hm = np.ctypeslib.as_array(d.group_hitmiss, shape=(8, stride, 2)) if stride else np.zeros((8, 0, 2), np.float32)
+    for code in range(8):
+        out[f"group_hitmiss_{code}"] = hm[code, :ng].reshape(-1).copy()
+    return out
 
 
 def trackball_motion(rotation, dx: float, dy: float):

@@ -17,6 +17,9 @@ bool g_host_quiet = false;
 struct shray_host_world {
     world_ptr w;
     std::vector<std::unique_ptr<scene_shader_data>> flat;   // every flattening handed out stays valid until the world is freed
+    // shray_host_export_tree
+    std::vector<int32_t> tree_parent, tree_negative, tree_positive, tree_start, tree_triangles, tri_vertices;
+    std::vector<float> tree_box, tree_direction;
     bvh_build_stats stats;
     double load_seconds = 0;
 };
@@ -92,6 +95,69 @@ int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width,
     desc->group_children = d.group_children;
     desc->group_hitmiss = d.group_hitmiss;
     desc->group_objects = d.group_objects;
+    return 0;
+}
+
+int shray_host_export_tree(shray_host_world *world, shray_tree_desc *tree)
+{
+    if (!world || !tree || !world->w || !world->w->root)
+        return -1;
+    // pre-order without recursion: a node, its negative subtree, its positive subtree
+    world->tree_parent.clear();
+    world->tree_negative.clear();
+    world->tree_positive.clear();
+    world->tree_start.clear();
+    world->tree_triangles.clear();
+    world->tree_box.clear();
+    world->tree_direction.clear();
+    struct pending {
+        const group *g;
+        int32_t parent;
+        bool positive_side;
+    };
+    std::vector<pending> todo(1, pending{world->w->root, -1, false});
+    while (!todo.empty()) {
+        const pending p = todo.back();
+        todo.pop_back();
+        const int32_t me = (int32_t)world->tree_parent.size();
+        world->tree_parent.push_back(p.parent);
+        world->tree_negative.push_back(-1);
+        world->tree_positive.push_back(-1);
+        if (p.parent >= 0)
+            (p.positive_side ? world->tree_positive : world->tree_negative)[(size_t)p.parent] = me;
+        const group *g = p.g;
+        const float box[6] = {g->box.boxmin.x, g->box.boxmin.y, g->box.boxmin.z, g->box.boxmax.x, g->box.boxmax.y, g->box.boxmax.z};
+        world->tree_box.insert(world->tree_box.end(), box, box + 6);
+        const float dir[3] = {g->D.x, g->D.y, g->D.z};
+        world->tree_direction.insert(world->tree_direction.end(), dir, dir + 3);
+        world->tree_start.push_back(g->is_leaf() ? g->start : 0);
+        world->tree_triangles.push_back(g->is_leaf() ? (int32_t)g->count : 0);
+        if (!g->is_leaf()) {
+            todo.push_back(pending{g->positive, me, true});
+            todo.push_back(pending{g->negative, me, false});
+        }
+    }
+    const triangle_set &mesh = *world->w->triangles;
+    world->tri_vertices.resize(3 * mesh.triangles.size());
+    for (size_t t = 0; t < mesh.triangles.size(); t++)
+        for (int corner = 0; corner < 3; corner++)
+            world->tri_vertices[3 * t + corner] = mesh.triangles[t].i[corner];
+    static_assert(sizeof(vertex) == 9 * sizeof(float), "vertex is nine packed floats: position, colour, normal");
+
+    memset(tree, 0, sizeof(*tree));
+    tree->struct_size = (uint32_t)sizeof(*tree);
+    tree->node_count = (int32_t)world->tree_parent.size();
+    tree->node_parent = world->tree_parent.data();
+    tree->node_negative = world->tree_negative.data();
+    tree->node_positive = world->tree_positive.data();
+    tree->node_box = world->tree_box.data();
+    tree->node_direction = world->tree_direction.data();
+    tree->node_start = world->tree_start.data();
+    tree->node_triangles = world->tree_triangles.data();
+    tree->triangle_count = (int32_t)mesh.triangles.size();
+    tree->triangle_vertices = world->tri_vertices.data();
+    tree->vertex_count = (int32_t)mesh.vertices.size();
+    tree->vertex_data = mesh.vertices.empty() ? nullptr : &mesh.vertices[0].v.x;
     return 0;
 }
 

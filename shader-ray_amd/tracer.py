@@ -95,6 +95,45 @@ class Scene:
             C.c_void_p(stream_ptr)))
 
 
+class DeviceFlat:
+    """get_shader_data on the GPU (shray_flatten_device): the flattened arrays of a host-built BVH, resident
+    on the device.  `download()` gives a SceneDesc with host pointers (owned by this object)."""
+
+    def __init__(self, tree: N.TreeDesc, data_texture_width: int = 2048):
+        self._lib = N.load_hip()
+        self._tree = tree
+        handle = C.c_void_p()
+        N.check(self._lib.shray_flatten_device(C.byref(tree), data_texture_width, C.byref(handle)))
+        self._handle = handle
+
+    def download(self) -> N.SceneDesc:
+        desc = N.SceneDesc()
+        N.check(self._lib.shray_device_flat_download(self._handle, C.byref(desc)))
+        desc._owner = self
+        return desc
+
+    def describe(self) -> N.SceneDesc:
+        desc = N.SceneDesc()
+        N.check(self._lib.shray_device_flat_describe(self._handle, C.byref(desc)))
+        desc._owner = self
+        return desc
+
+    def arrays(self) -> dict:
+        from .host import desc_arrays
+        return desc_arrays(self.download())
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.shray_device_flat_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PinnedFrame:
     """RGBA float32 [height, width, 4] in pinned host memory (shray_pinned_alloc): the destination of the
     PCIe-speed readback forms."""

@@ -140,8 +140,10 @@ typedef struct shray_frame_params {
 typedef struct shray_tile_set {
     int32_t tile_w;
     int32_t tile_h;
-    int32_t tile_stride;
+    int32_t tile_stride;       /* period: tile t belongs to this set when phase <= t % stride < phase + count */
     int32_t tile_phase;
+    int32_t tile_phase_count;  /* consecutive phases owned (0 means 1): ranks may own unequal shares of a frame,
+                                  e.g. rank 0, which also receives and de-interleaves, 2 of 23 and its peers 3 */
 } shray_tile_set;
 
 /* Work counters of one render, summed over all pixels and samples.  They feed
@@ -269,6 +271,13 @@ int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, i
                                 int64_t rank_stride_bytes, int64_t frame_stride_bytes,
                                 int width, int height, int tile_w, int tile_h,
                                 void *d_rgba_out, void *hip_stream);
+/* The same for unequal shares: the tile period is rank0_phases + (world - 1) * other_phases; rank 0 owns the
+ * first rank0_phases phases of every period, rank r >= 1 the other_phases phases from rank0_phases +
+ * (r - 1) * other_phases (shray_tile_set with that phase and count).  (1, 1) is the even split above. */
+int shray_assemble_tiles_split_device(const void *d_gathered, int world, int rank0_phases, int other_phases,
+                                      int frames, int channels, int64_t rank_stride_bytes, int64_t frame_stride_bytes,
+                                      int width, int height, int tile_w, int tile_h,
+                                      void *d_rgba_out, void *hip_stream);
 
 /* Same render with per-ray work counters accumulated (slower; used for the
  * roofline's algorithmic-byte count and for parity of the traversal itself). */

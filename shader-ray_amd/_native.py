@@ -48,7 +48,8 @@ class FrameParams(C.Structure):
 
 
 class TileSet(C.Structure):
-    _fields_ = [("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tile_stride", C.c_int32), ("tile_phase", C.c_int32)]
+    _fields_ = [("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tile_stride", C.c_int32), ("tile_phase", C.c_int32),
+                ("tile_phase_count", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -115,6 +116,8 @@ HIP_SYMBOLS = [
     ("shray_tile_buffer_bytes", C.c_int64, [C.c_int, C.c_int, C.POINTER(TileSet)]),
     ("shray_assemble_tiles_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("shray_assemble_tiles_split_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("shray_render_counters", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                         c_float_p, C.POINTER(Counters)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),

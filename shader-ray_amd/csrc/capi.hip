@@ -91,7 +91,10 @@ struct DeviceBuffer {
             return e;
         if (src)
             return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
-        return hipMemset(p, 0, bytes);
+        e = hipMemset(p, 0, bytes);
+        // the fill runs on the null stream, which non-blocking streams do not wait for: finish it here, before
+        // any kernel or copy on another stream can touch the buffer
+        return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
     }
 };
 
@@ -338,6 +341,12 @@ int validate_params(const shray_frame_params *p, int width, int height, int spp)
     return SHRAY_OK;
 }
 
+// tiles t < total with phase <= t % stride < phase + count
+int64_t owned_tile_count(int64_t total, int64_t stride, int64_t phase, int64_t count)
+{
+    return total / stride * count + std::min(count, std::max<int64_t>(0, total % stride - phase));
+}
+
 int make_frame_view(const shray_frame_params *p, int width, int height, int spp, const shray_tile_set *tiles,
                     FrameView *fr)
 {
@@ -373,21 +382,20 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
         fr->total_patches = (uint32_t)fr->patches_per_unit;
         return SHRAY_OK;
     }
+    const int phase_count = tiles->tile_phase_count > 0 ? tiles->tile_phase_count : 1;
     if (tiles->tile_w <= 0 || tiles->tile_h <= 0 || tiles->tile_w % 16 || tiles->tile_h % 16 ||
-        tiles->tile_phase < 0 || tiles->tile_phase >= tiles->tile_stride)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "tile set {%d x %d, stride %d, phase %d}: tile sizes must be positive "
-                    "multiples of 16 and 0 <= phase < stride", tiles->tile_w, tiles->tile_h, tiles->tile_stride,
-                    tiles->tile_phase);
+        tiles->tile_phase < 0 || tiles->tile_phase_count < 0 || tiles->tile_phase + phase_count > tiles->tile_stride)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "tile set {%d x %d, stride %d, phase %d, count %d}: tile sizes must be positive "
+                    "multiples of 16 and 0 <= phase, phase + count <= stride", tiles->tile_w, tiles->tile_h, tiles->tile_stride,
+                    tiles->tile_phase, phase_count);
     fr->tile_w = tiles->tile_w;
     fr->tile_h = tiles->tile_h;
     fr->tile_stride = tiles->tile_stride;
     fr->tile_phase = tiles->tile_phase;
+    fr->tile_phase_count = phase_count;
     fr->tiles_x = (width + tiles->tile_w - 1) / tiles->tile_w;
     const int tiles_y = (height + tiles->tile_h - 1) / tiles->tile_h;
-    const int64_t total_tiles = (int64_t)fr->tiles_x * tiles_y;
-    fr->owned_tiles = (int32_t)((total_tiles - tiles->tile_phase + tiles->tile_stride - 1) / tiles->tile_stride);
-    if (fr->owned_tiles < 0)
-        fr->owned_tiles = 0;
+    fr->owned_tiles = (int32_t)owned_tile_count((int64_t)fr->tiles_x * tiles_y, tiles->tile_stride, tiles->tile_phase, phase_count);
     fr->patches_x = tiles->tile_w / 16;
     fr->patches_per_unit = fr->patches_x * (tiles->tile_h / 16);
     fr->total_patches = (uint32_t)fr->owned_tiles * (uint32_t)fr->patches_per_unit;
@@ -696,11 +704,12 @@ int64_t shray_tile_buffer_bytes(int width, int height, const shray_tile_set *til
         return 0;
     if (!tiles || tiles->tile_stride <= 0)
         return (int64_t)width * height * 16;
-    if (tiles->tile_w <= 0 || tiles->tile_h <= 0 || tiles->tile_phase < 0 || tiles->tile_phase >= tiles->tile_stride)
+    const int phase_count = tiles->tile_phase_count > 0 ? tiles->tile_phase_count : 1;
+    if (tiles->tile_w <= 0 || tiles->tile_h <= 0 || tiles->tile_phase < 0 || tiles->tile_phase_count < 0 ||
+        tiles->tile_phase + phase_count > tiles->tile_stride)
         return 0;
     const int64_t tx = (width + tiles->tile_w - 1) / tiles->tile_w, ty = (height + tiles->tile_h - 1) / tiles->tile_h;
-    const int64_t owned = (tx * ty - tiles->tile_phase + tiles->tile_stride - 1) / tiles->tile_stride;
-    return std::max<int64_t>(owned, 0) * tiles->tile_w * tiles->tile_h * 16;
+    return owned_tile_count(tx * ty, tiles->tile_stride, tiles->tile_phase, phase_count) * tiles->tile_w * tiles->tile_h * 16;
 }
 
 int shray_render_device(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
@@ -768,35 +777,52 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     return launch_stack_views(scene, views.data(), count, (float4 *)d_rgba_out, (size_t)frame_stride_bytes / 16, stream);
 }
 
-int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, int channels, int64_t rank_stride_bytes,
-                                int64_t frame_stride_bytes, int width, int height, int tile_w, int tile_h,
-                                void *d_rgba_out, void *hip_stream)
+int shray_assemble_tiles_split_device(const void *d_gathered, int world, int rank0_phases, int other_phases, int frames,
+                                      int channels, int64_t rank_stride_bytes, int64_t frame_stride_bytes, int width, int height,
+                                      int tile_w, int tile_h, void *d_rgba_out, void *hip_stream)
 {
     if (!d_gathered || !d_rgba_out)
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "gathered or output buffer is NULL");
     if (world < 1 || frames < 1 || frames > 65535 || (channels != 3 && channels != 4) || width <= 0 || height <= 0 ||
-        width > 65536 || height > 65535 || tile_w <= 0 || tile_h <= 0)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad assemble geometry (world %d, %d frames, %d channels, %dx%d, tiles %dx%d)",
-                    world, frames, channels, width, height, tile_w, tile_h);
+        width > 65536 || height > 65535 || tile_w <= 0 || tile_h <= 0 || rank0_phases < 1 || other_phases < 1 ||
+        rank0_phases > 4096 || other_phases > 4096)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad assemble geometry (world %d, shares %d / %d, %d frames, %d channels, %dx%d, "
+                    "tiles %dx%d)", world, rank0_phases, other_phases, frames, channels, width, height, tile_w, tile_h);
     const int64_t tiles = (int64_t)((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
-    const int64_t frame_bytes = (tiles + world - 1) / world * tile_w * tile_h * channels * 4;
+    const int64_t period = rank0_phases + (int64_t)(world - 1) * other_phases;
+    int64_t most = owned_tile_count(tiles, period, 0, rank0_phases);
+    for (int r = 1; r < world; r++)
+        most = std::max(most, owned_tile_count(tiles, period, rank0_phases + (int64_t)(r - 1) * other_phases, other_phases));
+    const int64_t frame_bytes = most * tile_w * tile_h * channels * 4;
     if (frame_stride_bytes < frame_bytes || frame_stride_bytes % 4 || rank_stride_bytes % 4 ||
         rank_stride_bytes < (int64_t)(frames - 1) * frame_stride_bytes + frame_bytes)
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "strides too small: a rank's frame takes %lld bytes (frame stride %lld, "
                     "rank stride %lld)", (long long)frame_bytes, (long long)frame_stride_bytes, (long long)rank_stride_bytes);
-    const hipError_t e = launch_assemble_tiles((const float *)d_gathered, (float4 *)d_rgba_out, world, frames, channels, width,
-                                               height, tile_w, tile_h, (size_t)rank_stride_bytes / 4,
+    const hipError_t e = launch_assemble_tiles((const float *)d_gathered, (float4 *)d_rgba_out, world, rank0_phases, other_phases,
+                                               frames, channels, width, height, tile_w, tile_h, (size_t)rank_stride_bytes / 4,
                                                (size_t)frame_stride_bytes / 4, (hipStream_t)hip_stream);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     return SHRAY_OK;
 }
 
+int shray_assemble_tiles_device(const void *d_gathered, int world, int frames, int channels, int64_t rank_stride_bytes,
+                                int64_t frame_stride_bytes, int width, int height, int tile_w, int tile_h,
+                                void *d_rgba_out, void *hip_stream)
+{
+    return shray_assemble_tiles_split_device(d_gathered, world, 1, 1, frames, channels, rank_stride_bytes, frame_stride_bytes, width,
+                                             height, tile_w, tile_h, d_rgba_out, hip_stream);
+}
+
 namespace {
 int ensure_frame(shray_scene *scene, size_t bytes)
 {
     if (scene->frame_bytes < bytes) {
-        HIP_TRY(scene->frame.upload(nullptr, bytes));
+        // plain allocation: a fill on the null stream would not be ordered against the kernels that write the
+        // frame on other (non-blocking) streams, and every pixel is written by the render anyway
+        scene->frame.release();
+        scene->frame_bytes = 0;
+        HIP_TRY(hipMalloc(&scene->frame.p, bytes));
         scene->frame_bytes = bytes;
     }
     if (!scene->readback_stream)

@@ -65,7 +65,7 @@ struct FrameView {
 
     int32_t width, height, spp;
     // tiling: tile_stride == 0 means "whole frame, row-major output"
-    int32_t tile_w, tile_h, tile_stride, tile_phase;
+    int32_t tile_w, tile_h, tile_stride, tile_phase, tile_phase_count;   // owned: phase <= tile % stride < phase + count
     int32_t tiles_x;          // tiles per frame row
     int32_t owned_tiles;      // tiles this launch renders
     int32_t patches_x;        // 16x16 patches per row (of the frame, or of one tile)

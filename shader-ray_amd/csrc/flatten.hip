@@ -40,7 +40,7 @@ struct DeviceArray {
     hipError_t zeros(size_t bytes)
     {
         hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        return e != hipSuccess ? e : hipMemset(p, 0, bytes ? bytes : 16);
+        return e != hipSuccess ? e : hipMemset(p, 0, bytes ? bytes : 16);   // same (null) stream as the kernels below
     }
     hipError_t upload(const void *src, size_t bytes)
     {

@@ -36,8 +36,9 @@ hipError_t launch_pool_batch(const SceneView &sc, const FrameView *d_frames, int
 
 // rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,
 // frame_stride between a rank's consecutive frames
-hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, int frames, int channels, int width,
-                                 int height, int tile_w, int tile_h, size_t rank_stride, size_t frame_stride,
+// (c0, c1): phases per period owned by rank 0 / by every other rank (1, 1 = even split)
+hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, int c0, int c1, int frames, int channels,
+                                 int width, int height, int tile_w, int tile_h, size_t rank_stride, size_t frame_stride,
                                  hipStream_t stream);
 
 // Compares div_by_constant (exact_div.h) with true division on `pairs` pseudo-random

@@ -389,7 +389,8 @@ __device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int p
     } else {
         const unsigned int k = patch / (unsigned int)fr.patches_per_unit;
         const unsigned int q = patch % (unsigned int)fr.patches_per_unit;
-        const unsigned int tile = k * (unsigned int)fr.tile_stride + (unsigned int)fr.tile_phase;
+        const unsigned int pc = (unsigned int)fr.tile_phase_count;   // the set's k-th tile: period k / pc, phase offset k % pc
+        const unsigned int tile = (k / pc) * (unsigned int)fr.tile_stride + (unsigned int)fr.tile_phase + k % pc;
         const int tx = (int)(tile % (unsigned int)fr.tiles_x), ty = (int)(tile / (unsigned int)fr.tiles_x);
         const int tlx = (int)(q % (unsigned int)fr.patches_x) * 16 + lx;
         const int tly = (int)(q / (unsigned int)fr.patches_x) * 16 + ly;

@@ -80,6 +80,10 @@ def test_tile_buffer_bytes(pkg):
     # 7 tiles over 3 ranks: 3, 2, 2
     sizes = [tile_buffer_bytes(7 * 16, 16, N.TileSet(16, 16, 3, ph)) // (16 * 16 * 16) for ph in range(3)]
     assert sizes == [3, 2, 2]
+    # uneven shares: phases [0, 2) and [2, 5) of a period of 5 over 13 tiles -> 2+2+2 = 6 and 3+3+1 = 7 tiles
+    sizes = [tile_buffer_bytes(13 * 16, 16, N.TileSet(16, 16, 5, ph, cnt)) // (16 * 16 * 16) for ph, cnt in ((0, 2), (2, 3))]
+    assert sizes == [6, 7]
+    assert tile_buffer_bytes(64, 64, N.TileSet(16, 16, 5, 3, 3)) == 0     # phase + count beyond the period
 
 
 def test_argument_errors_are_reported_not_fatal(pkg):

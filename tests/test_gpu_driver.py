@@ -140,3 +140,43 @@ def test_config4_full_size_million_triangles_4spp(pkg, gpu, oracle_mod):
     scene.set_kernel(0)
     assert np.all(want[..., 3] == 1.0) and not np.isnan(want).any()
     scene.close()
+
+
+def test_uneven_rank_shares_on_one_gpu(pkg, gpu):
+    """Rank 0 owns fewer tiles than its peers (shray_tile_set.tile_phase_count, shray_assemble_tiles_split_device):
+    every rank's tile set rendered on this GPU, RGB on the wire, de-interleaved by the split kernel -- the frames
+    equal full-frame renders bit for bit; so does BASELINE config 5's shape (8 ranks, balanced shares) at 960x540."""
+    import ctypes as C
+    import torch
+    from shader_ray_amd import multigpu
+    N = pkg._native
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(128), device=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for (W, H, tile, ranks, shares, spp) in ((200, 136, 32, 3, (2, 3), 1), (333, 100, 16, 4, (3, 4), 2),
+                                             (960, 540, 32, 8, multigpu.balanced_shares(8), 4), (96, 64, 32, 2, (1, 5), 1)):
+        frames = [world.frame_params(W, H, material=m) for m in (0, 6)]
+        want = [scene.render(p, W, H, spp) for p in frames]
+        per = multigpu.max_tiles_per_rank(W, H, tile, tile, ranks, shares)
+        pixels = per * tile * tile
+        gathered = torch.zeros(ranks, 2, pixels * 3, dtype=torch.float32, device="cuda:0")
+        rgba = torch.zeros(2, pixels * 4, dtype=torch.float32, device="cuda:0")
+        for r in range(ranks):
+            period, phase, count = multigpu.rank_phases(ranks, r, shares)
+            tiles = N.TileSet(tile, tile, period, phase, count)
+            assert pkg.tracer.tile_buffer_bytes(W, H, tiles) <= pixels * 16
+            rgba.zero_()
+            scene.render_batch_into(frames, W, H, spp, rgba.data_ptr(), pixels * 16, stream, tiles)
+            gathered[r].view(2, pixels, 3).copy_(rgba.view(2, pixels, 4)[:, :, :3])
+        out = torch.zeros(2, H, W, 4, dtype=torch.float32, device="cuda:0")
+        N.check(N.load_hip().shray_assemble_tiles_split_device(
+            C.c_void_p(gathered.data_ptr()), ranks, shares[0], shares[1], 2, 3, gathered.stride(0) * 4, gathered.stride(1) * 4,
+            W, H, tile, tile, C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), (W, H, tile, ranks, shares, k)
+    # the object the bench uses, one rank: shares collapse to (1, 1)
+    assert multigpu.DistributedFrame(64, 64, 32, 32, device="cuda:0").shares == (1, 1)
+    with pytest.raises(N.ShrayError):
+        scene.render_into(world.frame_params(64, 64), 64, 64, 1, out.data_ptr(), stream, N.TileSet(32, 32, 4, 3, 2))
+    scene.close()

@@ -13,7 +13,7 @@ W, H = 1920, 1080
 if cfg == 4:
     world, env, material, spp = pkg.World(helpers.million_obj()), pkg.scenes.environment_hdr_sky(2048), 0, 4
 elif cfg == 3:
-    world, env, material, spp = pkg.World(helpers.bunny_trisrc()), pkg.scenes.environment_hdr_sky(2048), 3, 4
+    world, env, material, spp = pkg.World(helpers.bunny_trisrc()), pkg.scenes.environment_hdr_sky(2048), 6, 4
 else:
     world, env, material, spp = pkg.World(helpers.bunny_trisrc()), pkg.scenes.environment_constant(), 0, 1
 if len(sys.argv) > 2:

@@ -57,11 +57,11 @@ __device__ __forceinline__ StackTraversal<kBlock, DEAL> make_traversal(uint32_t 
 {
     StackTraversal<kBlock, DEAL> trav;
     trav.stack = lds + threadIdx.x;
-    trav.ids = lds + (size_t)stack_levels * kBlock + (threadIdx.x & ~63u);
+    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * kBlock) + (threadIdx.x & ~63u);
 #if SHRAY_LDS_TOP
     // experiment: the workgroup stages the top of the tree (the first SHRAY_LDS_TOP nodes, numbered breadth first
     // by capi.hip under the same flag) behind the stack columns and the id tables
-    float4 *top = reinterpret_cast<float4 *>(lds + (size_t)stack_levels * kBlock + kBlock);
+    float4 *top = reinterpret_cast<float4 *>(lds + (size_t)stack_levels * kBlock + kBlock / 4);
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
     for (unsigned int k = threadIdx.x; k < 2u * SHRAY_LDS_TOP && k < 2u * sc.group_count; k += kBlock)
         top[k] = nodes[k];
@@ -119,8 +119,9 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 
 static size_t stack_lds_bytes(int stack_levels)
 {
-    // stack columns + the dealt leaf stage's id tables (64 dwords per wave)
-    return ((size_t)kBlock * (size_t)stack_levels + kBlock) * sizeof(uint32_t) + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
+    // stack columns + the dealt leaf stage's id tables (64 bytes per wave): 26.25 KB for the 1M-triangle tree
+    // (26 levels), which lets six workgroups share a CU's 160 KB
+    return (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + kBlock + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
 }
 
 // `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;

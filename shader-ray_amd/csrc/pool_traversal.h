@@ -154,11 +154,7 @@ struct PoolTraversal {
                             const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
                             const float4 lo = nodes[2u * t.node];
                             const float4 hi = nodes[2u * t.node + 1u];
-#if SHRAY_LEAN_VISIT
-                            state = lane_visit_lean<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
-#else
                             state = lane_visit_loaded<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
-#endif
                         }
                     }
                     turns += 2;

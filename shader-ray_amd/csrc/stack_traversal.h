@@ -31,7 +31,7 @@ namespace shray {
 // in this traversal (at least SHRAY_KEEP_FLOOR) -- a wave with eight live lanes should not leave the node
 // loop after every visit; otherwise it is SHRAY_KEEP_WALKING lanes.  Swept in profiles/variant_sweep.sh.
 #ifndef SHRAY_KEEP_WALKING
-#define SHRAY_KEEP_WALKING 28
+#define SHRAY_KEEP_WALKING 36
 #endif
 constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
 // with the dealt leaf stage a leaf stage with few parked lanes is cheap, so the node loop may yield earlier
@@ -55,7 +55,7 @@ constexpr int kStackMinParked = SHRAY_MIN_PARKED;
 template <int BLOCK, bool DEAL = true>
 struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
-    uint32_t *ids;     // LDS, 64 dwords per wave: scratch of the dealt leaf stage (wave_traversal.h)
+    uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
     const float4 *top = nullptr;   // LDS copy of the first SHRAY_LDS_TOP packed nodes (experiment, else unused)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -44,7 +44,7 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with t
 #define SHRAY_LDS_TOP 0
 #endif
 #ifndef SHRAY_NODE_TURNS
-#define SHRAY_NODE_TURNS 2
+#define SHRAY_NODE_TURNS 3
 #endif
 
 #ifdef SHRAY_DIAGNOSTICS
@@ -125,8 +125,9 @@ __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, i
 }
 
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
-// (A fully predicated, branch-free form of the bookkeeping below was measured and is not faster:
-// the branches let the wave skip whole blocks with s_cbranch_execz.)
+// (A predicated form of the bookkeeping below -- every side effect once, under its own condition: 75 instead of
+// 96 vector instructions per visit in the ISA -- was measured in rounds 1 and 2 and is 3-8 % SLOWER on every
+// workload, profiles/r02/leaf_stage_ab.txt; the branches let the wave skip whole blocks with s_cbranch_execz.)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraversal &t, uint32_t *stack, RayCounters &rc,
                                                  const float4 lo, const float4 hi)
@@ -172,63 +173,6 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
         return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, true, neg_first ? neg_child : pos_child);
     }
     return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
-}
-
-// The same visit with its bookkeeping written as predicates and selects: every side effect (push, pop, link,
-// iteration cap, parking) appears once, under its own condition, instead of once per control-flow path --
-// the paths above are merged by the compiler with a register copy per live value and path (20 v_mov per visit).
-#ifndef SHRAY_LEAN_VISIT
-#define SHRAY_LEAN_VISIT 0
-#endif
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ int lane_visit_lean(const FrameView &fr, LaneTraversal &t, uint32_t *stack, RayCounters &rc,
-                                               const float4 lo, const float4 hi)
-{
-    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-    const bool leaf = (int32_t)b < 0;
-    if (COUNT) {
-        rc.node_visits++;
-        rc.leaf_visits += leaf ? 1u : 0u;   // the reference fetches (start, count) before the box test, fs:263-267
-    }
-    // range_intersect_box against [0, 1e8] (fs:200-217), as in lane_visit_loaded
-    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
-    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
-    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
-                     div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
-    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
-                     div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
-    if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
-        r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
-        r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
-    }
-    const bool entered = !(r0 >= r1) && (r0 < t.hit.t);
-    const uint32_t count = min(b & ~kLeafFlag, (uint32_t)fr.max_leaf_tests);
-    const bool park = entered && leaf && count > 0;      // the lane tests this leaf's triangles next
-    const bool descend = entered && !leaf;
-    const bool pop = !park && !descend;                   // missed, or an empty leaf: the next pending subtree
-    // branch: near child first, far child pending (packed_layout.h)
-    const uint32_t pos_child = a & kChildMask, neg_child = b;
-    const bool neg_first = (t.positive_dir >> (a >> 30)) & 1u;
-    const uint32_t near_child = neg_first ? neg_child : pos_child, far_child = neg_first ? pos_child : neg_child;
-    if (descend)
-        stack[t.sp * BLOCK] = far_child;
-    const bool take = pop && t.sp != 0;
-    uint32_t next = near_child;
-    if (take)
-        next = stack[(t.sp - 1) * BLOCK];
-    t.sp += descend ? 1 : (take ? -1 : 0);
-    t.node = park ? t.node : next;
-    t.leaf_first = park ? a : t.leaf_first;
-    t.leaf_count = park ? count : t.leaf_count;
-    t.leaf_r0 = park ? r0 : t.leaf_r0;
-    t.leaf_r1 = park ? r1 : t.leaf_r1;
-    t.leaf_j = 0;
-    // the visit is over unless the lane parked (then lane_advance runs after its triangles): link followed, cap applied
-    const bool finished = pop && !take;
-    const bool capped = !park && !finished && t.iter == fr.max_bvh_iterations - 1;   // set_bad_hit, fs:436-438
-    t.hit.t = capped ? -1.0f : t.hit.t;
-    t.iter += park ? 0 : 1;
-    return park ? LT_LEAF : ((finished || capped) ? LT_ENDED : LT_WALK);
 }
 
 template <bool COUNT, int BLOCK>
@@ -352,11 +296,7 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                 const float4 hi = nodes[2u * t.node + 1u];
 #endif
                 SHRAY_DIAG_WAIT(4);
-#if SHRAY_LEAN_VISIT
-                state = lane_visit_lean<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
-#else
                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
-#endif
             }
         }
         const int walking = __popcll(wave_ballot(state == LT_WALK));
@@ -484,10 +424,10 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
     return true;
 }
 
-// `ids`: 64 dwords of LDS owned by this wave (rank of a parked lane -> its lane number)
+// `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its lane number)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                                 uint32_t *stack, RayCounters &rc, uint32_t *ids SHRAY_DIAG_PARAM)
+                                                 uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
 {
     const unsigned long long parked = wave_ballot(state == LT_LEAF);
     if (!parked)
@@ -502,7 +442,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
     if (state == LT_LEAF)
-        ids[rank] = (uint32_t)lane;
+        ids[rank] = (uint8_t)lane;
     const int group = lane >> log_g, sub = lane & (G - 1);
     const bool worker = group < K;
     const int src = worker ? (int)ids[group] : lane;    // same wave, LDS operations complete in order

@@ -49,6 +49,9 @@ struct PoolTraversal {
     uint32_t *stack;    // LDS: levels x BLOCK, column-major ([level][column])
     uint32_t *xbuf;     // LDS: kPoolXbufDwords
     uint32_t *counts;   // LDS: kPoolCountDwords
+#ifdef SHRAY_DIAGNOSTICS
+    unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // Collective: every thread of the workgroup calls it (has_ray = this thread's pixel has a ray to trace).
     // Returns the number of rays the workgroup traced (uniform); `hit` is set for has_ray threads.
@@ -162,7 +165,7 @@ struct PoolTraversal {
                     if ((walking < keep && wave_ballot(state == LT_LEAF)) || turns >= kPoolEpochTurns)
                         break;
                 }
-                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, column, rc);
+                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, column, rc SHRAY_DIAG_ARG);
             }
 
             // ---- a ray that ended in this epoch leaves its hit in the first four levels of its own column

@@ -16,6 +16,10 @@ template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool)
 {
+#ifdef SHRAY_DIAGNOSTICS
+    // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a buffer nothing else reads
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     int px, py;
     size_t out_index;
     bool store, inside;
@@ -111,6 +115,20 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
     if (store)
         out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+#ifdef SHRAY_DIAGNOSTICS
+    if (counters && (threadIdx.x & 63u) == 0) {
+        unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        unsigned int hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        tl[0] = t_begin;
+        tl[1] = __builtin_amdgcn_s_memrealtime();
+        tl[2] = ((unsigned long long)xcc_id << 32) | hw_id;
+        tl[3] = rc.node_visits;
+        for (int k = 0; k < 8; k++)
+            tl[4 + k] = pool.diag_tally[k];
+    }
+#endif
     if (COUNT)
         add_counters(rc, counters);
 }

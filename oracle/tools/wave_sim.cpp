@@ -36,6 +36,7 @@ struct Policy {
     int epoch_turns;      // > 0: the workgroup's waves meet every epoch_turns node turns and repack their live rays
                           //      into fewer waves whenever they fit (mid-traversal compaction; needs compact = 1)
     int epoch_slack;      // repack only when at least this many lanes would be freed beyond a whole wave
+    int interleave;       // 1: wave w of a patch takes the pixels with (x & 1) + 2 (y & 1) == w instead of an 8x8 tile
 };
 
 struct Ray {
@@ -442,8 +443,13 @@ extern "C" int wave_sim(const uint8_t *bytes, const uint64_t *offsets, int W, in
             for (int w = 0; w < 4; w++)
                 for (int l = 0; l < 64; l++) {
                     const int s = w * 64 + l;
-                    px[s] = gx * 16 + (w & 1) * 8 + (l & 7);
-                    py[s] = gy * 16 + (w >> 1) * 8 + (l >> 3);
+                    if (pol.interleave) {
+                        px[s] = gx * 16 + 2 * (l & 7) + (w & 1);
+                        py[s] = gy * 16 + 2 * (l >> 3) + (w >> 1);
+                    } else {
+                        px[s] = gx * 16 + (w & 1) * 8 + (l & 7);
+                        py[s] = gy * 16 + (w >> 1) * 8 + (l >> 3);
+                    }
                     inside[s] = px[s] < W && py[s] < H;
                 }
             for (int smp = 0; smp < spp; smp++) {

@@ -188,8 +188,23 @@ def test_full_size_properties_1080p(pkg, gpu, oracle_mod, bunny, env_sky):
     a2 = scene.render(params, W, H, 1)
     scene.set_kernel(1)
     b, cb = scene.render_counters(params, W, H, 1)
+    scene.set_kernel(2)      # pool kernel: the workgroup's waves merge their live rays mid-traversal
+    c, cc = scene.render_counters(params, W, H, 1)
+    c2 = scene.render(params, W, H, 1)
     scene.set_kernel(0)
     assert np.array_equal(a, a2) and np.array_equal(a, b) and ca == cb
+    assert np.array_equal(a, c) and np.array_equal(c, c2) and ca == cc
+    # the stack kernel's two gold instances (capi.hip: leaf_stage_policy): one frame per launch runs the dealt
+    # leaf stage, two frames per launch the plain leaf loop -- the same frame either way, on two streams at once
+    import torch
+    pair = torch.empty(2, H * W * 4, dtype=torch.float32, device="cuda:0")
+    lone = torch.empty(H * W * 4, dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    scene.render_batch_into([params, params], W, H, 1, pair.data_ptr(), H * W * 16, torch.cuda.current_stream().cuda_stream)
+    scene.render_into(params, W, H, 1, lone.data_ptr(), side.cuda_stream)
+    torch.cuda.synchronize()
+    for frame in (pair[0], pair[1], lone):
+        assert np.array_equal(frame.cpu().numpy().reshape(H, W, 4), a)
     assert np.all(a[..., 3] == 1.0) and not np.isnan(a).any()
     assert ca["samples"] == W * H and ca["bad_hits"] == 0
     rows = (520, 560)    # through the middle of the object

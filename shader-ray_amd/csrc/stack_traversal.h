@@ -1,5 +1,5 @@
 // stack_traversal.h -- per-ray stack traversal over the packed layout (packed_layout.h),
-// one traversal per lane at a time (used by kernel_stack.hip through trace_common.h).
+// one traversal per lane at a time (used by kernel_stack.hip through uniform_driver.h / trace_common.h).
 // Same visits, same order, same arithmetic as the reference's threaded traversal
 // (raytracer.es.fs:386-443); what changes is where the data comes from and how the wave
 // schedules the work:
@@ -11,25 +11,18 @@
 //     correctly rounded reciprocal plus two FMA refinements that land on the same correctly
 //     rounded quotient (exact_div.h); rays or scenes outside the proven operand ranges keep
 //     dividing
-//   * node visits and triangle tests are single steps of one wave-cooperative loop
-//     (wave_traversal.h: walk_stage) so that one lane's leaf does not stall the other 63
+//   * node visits and triangle tests are stages of one wave-cooperative loop (wave_traversal.h: inner_stage,
+//     leaf_stage / leaf_stage_dealt) so that one lane's leaf does not stall the other 63
 #pragma once
 
 #include "wave_traversal.h"
 
 namespace shray {
 
-// Two equivalent schedules of the same per-lane program (wave_traversal.h); measured on the
-// 1080p bunny frame they are within 3 % of each other (0.64 vs 0.66 ms):
-//   default            node loop, then the parked lanes' leaf loops        (inner_stage + leaf_stage)
-//   SHRAY_UNIFIED_WALK one node step and one triangle step per iteration   (walk_stage)
-#ifndef SHRAY_UNIFIED_WALK
-#define SHRAY_UNIFIED_WALK 0
-#endif
 // The node loop yields to the leaf stage (when lanes are parked) once fewer than a threshold of lanes
 // are still walking.  SHRAY_RELATIVE_KEEP: the threshold is SHRAY_KEEP_WALKING / 64 of the lanes still
 // in this traversal (at least SHRAY_KEEP_FLOOR) -- a wave with eight live lanes should not leave the node
-// loop after every visit; otherwise it is SHRAY_KEEP_WALKING lanes.  Swept in profiles/variant_sweep.sh.
+// loop after every visit; otherwise it is SHRAY_KEEP_WALKING lanes.  Swept in profiles/variant_probe3.sh.
 #ifndef SHRAY_KEEP_WALKING
 #define SHRAY_KEEP_WALKING 36
 #endif
@@ -45,12 +38,6 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #ifndef SHRAY_KEEP_FLOOR
 #define SHRAY_KEEP_FLOOR 2
 #endif
-// parked lanes required before walk_stage spends instructions on a triangle step while others walk
-#ifndef SHRAY_MIN_PARKED
-#define SHRAY_MIN_PARKED 1
-#endif
-constexpr int kStackMinParked = SHRAY_MIN_PARKED;
-
 // DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
 template <int BLOCK, bool DEAL = true>
 struct StackTraversal {
@@ -94,15 +81,6 @@ struct StackTraversal {
     template <bool COUNT, bool CONVERGED>
     __device__ __forceinline__ void run(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state, RayCounters &rc)
     {
-#if SHRAY_UNIFIED_WALK
-#ifdef SHRAY_DIAGNOSTICS
-        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
-        walk_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackMinParked SHRAY_DIAG_ARG);
-#ifdef SHRAY_DIAGNOSTICS
-        diag_tally[2] += __builtin_amdgcn_s_memtime() - c0;
-#endif
-#else
         do {
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
@@ -128,7 +106,6 @@ struct StackTraversal {
             diag_tally[3] += c2 - c1;
 #endif
         } while (wave_ballot(state != LT_ENDED));
-#endif
     }
 };
 

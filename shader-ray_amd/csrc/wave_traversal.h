@@ -10,12 +10,13 @@
 //
 //   inner_stage   lanes in WALK visit one node each (slab test, push far child / pop, the
 //                 iteration-cap bookkeeping); a lane whose leaf box is hit parks in LEAF
-//   leaf_stage    all parked lanes run their triangle loops together, then move on
+//   leaf_stage    all parked lanes run their triangle loops together, then move on; or
+//   leaf_stage_dealt  the parked lanes' triangles are dealt to the wave's idle lanes (round 2)
 //
-// The node loop keeps running while enough lanes are still walking (kKeepWalking) and hands
-// over to the leaf stage once most lanes are parked, so triangle tests run with many lanes
-// active instead of one or two.  Used by kernel_stack.hip (one traversal per lane at a time)
-// and kernel_persistent.hip (lanes also in FETCH / SHADE states).
+// The node loop keeps running while enough lanes are still walking and hands over to the leaf
+// stage once enough lanes are parked, so triangle tests run with many lanes active instead of one
+// or two.  Used by kernel_stack.hip (a wave keeps its rays) and kernel_pool.hip (the waves of a
+// workgroup merge their rays between epochs).
 //
 // Arithmetic, visit order and iteration counting are exactly those of stack_traversal.h's
 // first version and of the literal threaded kernel; tests require bit-identical frames and
@@ -28,24 +29,20 @@
 
 namespace shray {
 
-enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };   // values shared with the persistent kernel's phases
+enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3 };
 
-// Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
-// cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
-// leaf_stage tests two triangles of a leaf per turn (1) or one (0).  Fewer instructions, more registers:
-// ahead at four waves per SIMD, behind at the six the stack kernel asks for (kernel_stack.hip)
-#ifndef SHRAY_LEAF_PAIRS
-#define SHRAY_LEAF_PAIRS 0
-#endif
-
-// node visits per lane between two evaluations of inner_stage's exit tests (same trade as above)
 // experiment: stage the first SHRAY_LDS_TOP packed nodes in LDS (0 = off, the shipped form)
 #ifndef SHRAY_LDS_TOP
 #define SHRAY_LDS_TOP 0
 #endif
+// node visits per lane between two evaluations of inner_stage's exit tests (fewer instructions against more
+// registers; three measured best in round 2, profiles/r02/leaf_stage_ab.txt)
 #ifndef SHRAY_NODE_TURNS
 #define SHRAY_NODE_TURNS 3
 #endif
+
+// Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
+// cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
 
 #ifdef SHRAY_DIAGNOSTICS
 #define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -73,7 +70,7 @@ struct LaneTraversal {
     uint32_t node;
     int sp, iter;
     float leaf_r0, leaf_r1;
-    uint32_t leaf_first, leaf_count, leaf_j;   // leaf_j: next triangle of the leaf (walk_stage)
+    uint32_t leaf_first, leaf_count;
 };
 
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -160,7 +157,6 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
                 t.leaf_count = count;
                 t.leaf_r0 = r0;
                 t.leaf_r1 = r1;
-                t.leaf_j = 0;
                 return LT_LEAF;
             }
             return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
@@ -213,34 +209,6 @@ __device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint
     t.hit.t = dist;
     t.hit.bu = u;
     t.hit.bv = w;
-}
-
-// triangle_intersect without the store and without the `d > hit.t` early-out: the candidate
-// (dist, u, w) of triangle data q0..q2 against the lane's ray; returns whether it passes every
-// other early-out of fs:312-340 (the predicate is a conjunction, so their order does not matter;
-// NaN operands fail the same comparisons as upstream).  Two of these are independent instruction
-// chains, which is what a wave running alone on its SIMD needs (leaf_stage).
-__device__ __forceinline__ bool lane_triangle_candidate(const LaneTraversal &t, const float4 q0, const float4 q1,
-                                                        const float4 q2, float &dist, float &u, float &w)
-{
-    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
-    const V3 M = cross3(e1, t.D);
-    const float det = dot3(e0, M);
-    const float inv_det = 1.0f / det;
-    const V3 T = t.P - v0;
-    const V3 Q = cross3(T, e0);
-    dist = -dot3(e1, Q) * inv_det;
-    u = dot3(T, M) * inv_det;
-    w = dot3(t.D, Q) * inv_det;
-    if (det > -0.0000001f && det < 0.0000001f)
-        return false;
-    if (dist < t.leaf_r0 || dist > t.leaf_r1)
-        return false;
-    if (u < 0.0f || u > 1.0f)
-        return false;
-    if (w < 0.0f || u + w > 1.0f)
-        return false;
-    return true;
 }
 
 // The three 16-byte words of a packed triangle, fetched as three dwordx4 loads issued back to
@@ -321,42 +289,6 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
         diag_tally_ref[7] += (total + 63u) / 64u;
     }
 #endif
-#if SHRAY_LEAF_PAIRS
-    // two triangles per turn: both loads issued together, the two tests are independent chains;
-    // the second is applied after the first, against the hit.t the first may have set (fs:416-424 order)
-    for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j += 2) {
-        SHRAY_DIAG_COUNT(1);
-        if (state == LT_LEAF && j < t.leaf_count) {
-            const bool second = j + 1 < t.leaf_count;
-            const float4 *tri = reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * (t.leaf_first + j);
-            float4 a0, a1, a2, b0, b1, b2;
-            SHRAY_DIAG_T0
-            load_packed_triangle(tri, a0, a1, a2);
-            load_packed_triangle(tri + (second ? 3 : 0), b0, b1, b2);
-            SHRAY_DIAG_WAIT(5);
-            if (COUNT)
-                rc.triangle_tests += second ? 2 : 1;
-            float da, ua, wa, db, ub, wb;
-            const bool pass_a = lane_triangle_candidate(t, a0, a1, a2, da, ua, wa);
-            const bool pass_b = lane_triangle_candidate(t, b0, b1, b2, db, ub, wb) && second;
-            if (pass_a && !(da > t.hit.t)) {
-                t.hit.which = (float)(t.leaf_first + j);
-                t.hit.t = da;
-                t.hit.bu = ua;
-                t.hit.bv = wa;
-            }
-            if (pass_b && !(db > t.hit.t)) {   // against the hit.t the first triangle may just have set
-                t.hit.which = (float)(t.leaf_first + j + 1);
-                t.hit.t = db;
-                t.hit.bu = ub;
-                t.hit.bv = wb;
-            }
-        }
-    }
-    if (state == LT_LEAF)
-        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
-    return;
-#endif
     for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
         SHRAY_DIAG_COUNT(1);
         if (state == LT_LEAF && j < t.leaf_count) {
@@ -400,7 +332,9 @@ __device__ __forceinline__ float lane_pull(int src_lane, float v)
 }
 __device__ __forceinline__ int lane_pull(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
-// lane_triangle_candidate for a ray held in plain values (the worker's copy of another lane's ray)
+// triangle_intersect without the store and without the `d > hit.t` early-out, for a ray held in plain values
+// (the worker's copy of another lane's ray): the candidate (dist, u, w) and whether it passes every other early-out of
+// fs:312-340 (a conjunction, so their order does not matter; NaN operands fail the same comparisons as upstream)
 __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r1, const float4 q0, const float4 q1,
                                                    const float4 q2, float &dist, float &u, float &w)
 {
@@ -499,57 +433,6 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
             t.hit.bv = ww;
         }
         state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
-    }
-}
-
-// One unified step: each walking lane visits ONE node and -- when at least `min_parked` lanes
-// are parked in a leaf, or nobody is walking -- each parked lane tests ONE triangle of its
-// leaf.  Both kinds of loads are issued together at the top.  Per-lane order of visits and
-// tests is unchanged; a lane resumes walking as soon as ITS leaf is done.
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ void walk_step(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                          uint32_t *stack, RayCounters &rc, unsigned long long walkers,
-                                          unsigned long long parked, int min_parked SHRAY_DIAG_PARAM)
-{
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.packed_tris);
-    const bool test_now = parked && (__popcll(parked) >= min_parked || !walkers);
-    const bool w = state == LT_WALK;
-    const bool p = test_now && state == LT_LEAF;
-    SHRAY_DIAG_COUNT(0);
-    if (test_now)
-        SHRAY_DIAG_COUNT(1);
-
-    float4 lo = make_float4(0, 0, 0, 0), hi = lo, q0 = lo, q1 = lo, q2 = lo;
-    const uint32_t which = t.leaf_first + t.leaf_j;
-    if (w) {
-        lo = nodes[2u * t.node];
-        hi = nodes[2u * t.node + 1u];
-    }
-    if (p) {
-        load_packed_triangle(tris + 3u * which, q0, q1, q2);
-    }
-    if (w)
-        state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
-    if (p) {
-        lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
-        t.leaf_j++;
-        if (t.leaf_j == t.leaf_count)
-            state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
-    }
-}
-
-// Unified loop: walk_step until every lane's traversal has ended.
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ void walk_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                           uint32_t *stack, RayCounters &rc, int min_parked SHRAY_DIAG_PARAM)
-{
-    for (;;) {
-        const unsigned long long walkers = wave_ballot(state == LT_WALK);
-        const unsigned long long parked = wave_ballot(state == LT_LEAF);
-        if (!(walkers | parked))
-            return;
-        walk_step<COUNT, BLOCK>(sc, fr, t, state, stack, rc, walkers, parked, min_parked SHRAY_DIAG_ARG_FWD);
     }
 }
 

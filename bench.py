@@ -10,7 +10,8 @@ renders its interleaved tiles with the HIP kernel and (N > 1) the packed tile bu
 gathered to rank 0 over RCCL and de-interleaved.  Scene and environment are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Successive frames are independent.  N = 1: two frames in flight on two HIP streams.  N > 1: a
+Successive frames are independent.  N = 1: the frame loop hands the C ABI two frames per launch and
+alternates launches over four HIP streams (profiles/r02/leaf_stage_ab.txt section 10).  N > 1: a
 launch carries N consecutive frames (the rank's tiles of each; shray_render_batch_device), one
 gather moves all N, and two such launches alternate on two streams -- a rank's share of ONE
 frame is latency-bound, see DESIGN.md section 6.  Exactly K frames are rendered in the timed
@@ -82,11 +83,12 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="frame width (default: the headline configuration)")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel; --width 3840 --height 2160 --spp 16 is BASELINE configs[4]")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="independent frames (N > 1: launches) alternate over this many HIP streams (1 = strictly one at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="independent launches alternate over this many HIP streams (1 = strictly one at a time; "
+                         "default: 4 for N = 1, 2 for N > 1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="N > 1 only: consecutive frames a rank renders in one launch and sends in one gather "
-                         "(default: the number of GPUs, so a launch always carries one frame's worth of pixels per GPU)")
+                    help="consecutive frames per launch (shray_render_batch_device); N > 1: also per gather.  Default: 2 for "
+                         "N = 1, the number of GPUs for N > 1 (a launch then carries one frame's worth of pixels per GPU)")
     ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: gather RGBA instead of RGB (alpha is the constant 1)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
@@ -144,7 +146,7 @@ def main():
     # frames over two HIP streams (double buffering, as any frame loop does) lets frame k+1's bulk
     # fill frame k's tail -- and, with several GPUs, lets the gather of frame k overlap the render
     # of frame k+1.  Every frame is still rendered completely into its own buffer.
-    lanes = max(1, args.frames_in_flight)
+    lanes = max(1, args.frames_in_flight or (2 if distributed else 4))
     # N > 1: a rank's share of one 1080p frame is latency-bound (its long-running waves take ~0.5 ms
     # wherever they land), so a launch carries `batch` consecutive frames (shray_render_batch_device) and
     # one gather moves them all: fewer, larger collectives, and the GPU stays full.

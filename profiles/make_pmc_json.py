@@ -34,7 +34,7 @@ fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 out = {
     "kernel": want,
     "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_per_launch": frames_per_launch,
-                 "streams": 2},
+                 "streams": int(sys.argv[5]) if len(sys.argv) > 5 else 4},
     "build_hash": kernel_source_hash(),
     "kernel_trace_avg_us": avg_us, "kernel_trace_calls": calls,
     "counters_per_launch": vals,

@@ -37,6 +37,7 @@ struct Policy {
                           //      into fewer waves whenever they fit (mid-traversal compaction; needs compact = 1)
     int epoch_slack;      // repack only when at least this many lanes would be freed beyond a whole wave
     int interleave;       // 1: wave w of a patch takes the pixels with (x & 1) + 2 (y & 1) == w instead of an 8x8 tile
+    int split_heavy;      // > 0: a wave whose stream exceeds this many instructions is replayed as four waves of 16 rays
 };
 
 struct Ray {
@@ -621,6 +622,51 @@ extern "C" int wave_sim(const uint8_t *bytes, const uint64_t *offsets, int W, in
                     phase_max = c.env;
                 }
                 group_path += phase_max;
+            }
+            if (pol.split_heavy > 0 && !pol.compact && spp == 1) {
+                // replay heavy waves as four waves of 16 rays (quarters of the 8x8 tile, 4x4 pixels each)
+                for (int w = 0; w < 4; w++) {
+                    if (wave_stream[w] <= pol.split_heavy)
+                        continue;
+                    double worst = 0;
+                    Totals scratch;
+                    for (int q = 0; q < 4; q++) {
+                        const uint8_t *cursor[16], *send[16];
+                        bool live[16];
+                        int n = 0;
+                        for (int l = 0; l < 64; l++) {
+                            const int lx = l & 7, ly = l >> 3;
+                            if ((lx >> 2) + 2 * (ly >> 2) != q)
+                                continue;
+                            const int s2 = w * 64 + l;
+                            live[n] = inside[s2];
+                            if (inside[s2]) {
+                                const size_t idx = ((size_t)py[s2] * W + px[s2]) * spp;
+                                cursor[n] = bytes + offsets[idx];
+                                send[n] = bytes + offsets[idx + 1];
+                            }
+                            n++;
+                        }
+                        double stream = c.gen + c.env;
+                        for (;;) {
+                            Ray lane_rays[64];
+                            int m = 0;
+                            for (int i = 0; i < 16; i++)
+                                if (live[i]) {
+                                    Ray r;
+                                    live[i] = next_traversal(cursor[i], send[i], r);
+                                    if (live[i])
+                                        lane_rays[m++] = r;
+                                }
+                            if (!m)
+                                break;
+                            stream += c.setup + c.shade + traverse(c, pol, lane_rays, m, scratch);
+                        }
+                        worst = std::max(worst, stream);
+                        t.other_w += stream;   // the extra waves' instructions (the original wave's stay counted: an upper bound)
+                    }
+                    wave_stream[w] = worst;
+                }
             }
             for (int w = 0; w < 4; w++)
                 wave_streams[gi * 4 + w] = wave_stream[w];

@@ -25,7 +25,7 @@ class Costs(C.Structure):
 
 
 class Policy(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("keep_num", "keep_floor", "node_turns", "deal_max_parked", "compact", "deal_group", "async_lanes", "event_min", "pixels_per_wave", "epoch_turns", "epoch_slack", "interleave")]
+    _fields_ = [(n, C.c_int) for n in ("keep_num", "keep_floor", "node_turns", "deal_max_parked", "compact", "deal_group", "async_lanes", "event_min", "pixels_per_wave", "epoch_turns", "epoch_slack", "interleave", "split_heavy")]
 
 
 def run(prefix, costs, policy):
@@ -60,7 +60,7 @@ if __name__ == "__main__":
     prefix = sys.argv[1]
     costs = Costs(gen=90, setup=70, node=95, tri=62, shade=120, env=220, stage_switch=8, loop_iter=10,
                   deal_setup=30, deal_round=85, deal_finish=35, compact=60, event=280)
-    base = dict(keep_num=28, keep_floor=2, node_turns=2, deal_max_parked=0, compact=0, deal_group=0, async_lanes=0, event_min=16, pixels_per_wave=64, epoch_turns=0, epoch_slack=0, interleave=0)
+    base = dict(keep_num=28, keep_floor=2, node_turns=2, deal_max_parked=0, compact=0, deal_group=0, async_lanes=0, event_min=16, pixels_per_wave=64, epoch_turns=0, epoch_slack=0, interleave=0, split_heavy=0)
     variants = [("current (keep 28/64, 2 node turns)", {})]
     for kn in (16, 40, 48):
         variants.append((f"keep {kn}/64", dict(keep_num=kn)))
@@ -88,6 +88,8 @@ if __name__ == "__main__":
         variants.append((f"epoch {et} slack 32 + dealt always keep 48", dict(compact=1, epoch_turns=et, epoch_slack=32, deal_max_parked=64, keep_num=48)))
     variants.append(("dealt always keep 48, interleaved waves", dict(deal_max_parked=64, keep_num=48, interleave=1)))
     variants.append(("current, interleaved waves", dict(interleave=1)))
+    for thr in (20000, 30000, 40000):
+        variants.append((f"dealt always keep 48, heavy waves (> {thr}) split in 4", dict(deal_max_parked=64, keep_num=48, split_heavy=thr)))
     if os.environ.get("ONLY"):
         variants = [v for v in variants if os.environ["ONLY"] in v[0] or v[0].startswith("current")]
     for label, over in variants:

@@ -180,3 +180,32 @@ def test_uneven_rank_shares_on_one_gpu(pkg, gpu):
     with pytest.raises(N.ShrayError):
         scene.render_into(world.frame_params(64, 64), 64, 64, 1, out.data_ptr(), stream, N.TileSet(32, 32, 4, 3, 2))
     scene.close()
+
+
+@pytest.mark.parametrize("material", [0, 6])
+def test_shader_constants_as_parameters(pkg, gpu, oracle_mod, material):
+    """The shader's compile-time constants are frame parameters here (raytracer.es.fs:550, :381, :382, :445): the
+    convergent bounce loop and the dealt leaf stage follow them exactly like the oracle does -- no bounce at all,
+    two bounces, a leaf cap of 3 and of 0, a tight iteration cap, no shadow rays -- frames and counters equal for
+    every kernel."""
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(128)
+    scene = pkg.Scene(desc, env, device=0)
+    W, H = 120, 72
+    variants = [dict(bounce_count=0), dict(bounce_count=2), dict(max_leaf_tests=3), dict(max_leaf_tests=0),
+                dict(max_bvh_iterations=12), dict(cast_shadows=0, bounce_count=5), dict(tonemap=0)]
+    for spp in (1, 2):
+        for overrides in variants:
+            params = world.frame_params(W, H, material=material)
+            for key, value in overrides.items():
+                setattr(params, key, value)
+            want, cpu = oracle_mod.render(desc, env, params, W, H, spp)
+            for kernel in (0, 1, 2):
+                scene.set_kernel(kernel)
+                got, counters = scene.render_counters(params, W, H, spp)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (overrides, spp, kernel)
+                assert counters == cpu, (overrides, spp, kernel)
+                assert np.array_equal(scene.render(params, W, H, spp), got), (overrides, spp, kernel)
+    scene.set_kernel(0)
+    scene.close()

@@ -276,7 +276,6 @@ def main():
         result["roofline"] = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Gwaveinst/s", "frac": None,
                               "traffic": None, "traffic_source": "not collected for N > 1 (see the N = 1 line)",
                               "algorithmic_cacheless": {"bytes_per_frame": algo_bytes, "gbs_per_gpu": round(per_gpu, 2),
-                                                        "x_hbm_peak": round(per_gpu / HBM_PEAK_GBS, 4),
                                                         "note": "cache-less count of the reference's fetches / wall time / n_gpus "
                                                                 "(gather and de-interleave included in the time); not a bound"}}
         result["counters"] = counters
@@ -326,9 +325,9 @@ def main():
         algo_gbs = algo_bytes * frames_per_s / 1e9
         roof["algorithmic_cacheless"] = {
             "bytes_per_frame": algo_bytes, "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
-            "gbs": round(algo_gbs, 2), "x_hbm_peak": round(algo_gbs / HBM_PEAK_GBS, 4),
+            "gbs": round(algo_gbs, 2),
             "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x frames / wall time; these bytes are served by "
-                    "L1/L2, so this is not a bound and may exceed the HBM peak"}
+                    "L1/L2, not by HBM: not a bound (it exceeds the 8000 GB/s HBM peak), no fraction is formed from it"}
         roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                      "concurrent_launches": lanes, "frames_per_launch": batch})
         result["roofline"] = roof

@@ -19,7 +19,7 @@ namespace shray {
 // "Packed layout" (built once at scene_create, used by the stack kernel; see
 // DESIGN.md "Data layout in HBM"):
 //   nodes       32 B per node, depth-first order, near/far resolved per ray
-//   tris        48 B per triangle: v0, e0 = v1 - v0, e1 = v0 - v2 (+ original index)
+//   tris        36 B per triangle: v0, e0 = v1 - v0, e1 = v0 - v2
 struct SceneView {
     const float *positions;
     const uint16_t *normals16;

@@ -9,8 +9,9 @@
 //     lo = { boxmin.xyz, a }      hi = { boxmax.xyz, b }
 //     branch: a = (split_axis << 30) | positive_child      b = negative_child
 //     leaf  : a = first triangle                            b = 0x80000000 | count
-//   PackedTri (48 B, same triangle order as the reference arrays)
-//     { v0.xyz, e0.x } { e0.yz, e1.xy } { e1.z, 0, 0, 0 }   e0 = v1 - v0, e1 = v0 - v2
+//   PackedTri (36 B, same triangle order as the reference arrays; three 12-byte loads per test)
+//     { v0.xyz } { e0.xyz } { e1.xyz }   e0 = v1 - v0, e1 = v0 - v2
+//     (48-byte records read as three dwordx4 measure 1.5-2 % slower: profiles/r02/leaf_stage_ab.txt)
 //
 // e0 / e1 are the same single fp32 subtractions triangle_intersect performs
 // per test (raytracer.es.fs:304-305), hoisted to scene-creation time.
@@ -38,9 +39,8 @@ struct PackedTri {
     float v0[3];
     float e0[3];
     float e1[3];
-    float pad[3];
 };
-static_assert(sizeof(PackedTri) == 48, "PackedTri must be 48 bytes");
+static_assert(sizeof(PackedTri) == 36, "PackedTri must be 36 bytes");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kChildMask = 0x3fffffffu;

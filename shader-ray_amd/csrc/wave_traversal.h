@@ -211,24 +211,29 @@ __device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint
     t.hit.bv = w;
 }
 
-// The three 16-byte words of a packed triangle, fetched as three dwordx4 loads issued back to
-// back.  (Left to itself the compiler splits them into partial loads and sinks some behind the
-// `det` early-out of the test, which costs a second dependent memory round trip per triangle.)
-__device__ __forceinline__ void load_packed_triangle(const float4 *tri, float4 &q0, float4 &q1, float4 &q2)
+// The nine floats of a packed triangle, fetched as three 12-byte loads issued back to back and handed on as the
+// three words {v0, e0.x} {e0.yz, e1.xy} {e1.z} the tests unpack.  (Left to itself the compiler splits the loads and
+// sinks part of them behind the `det` early-out of the test, which costs a second dependent memory round trip per
+// triangle: hence the pin below.)
+struct PackedF3 {
+    float x, y, z;
+};
+__device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
 {
-    q0 = tri[0];
-    q1 = tri[1];
-    q2 = tri[2];
-    // pin all twelve components here: whole-word loads, nothing deferred past a branch
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                 "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+    const PackedF3 *p = reinterpret_cast<const PackedF3 *>(sc.packed_tris) + 3u * index;
+    const PackedF3 a = p[0], b = p[1], c = p[2];
+    q0 = make_float4(a.x, a.y, a.z, b.x);
+    q1 = make_float4(b.y, b.z, c.x, c.y);
+    q2 = make_float4(c.z, 0.0f, 0.0f, 0.0f);
+    // pin the nine components here: whole loads, nothing deferred past a branch
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x));
 }
 
 template <bool COUNT>
 __device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc)
 {
     float4 q0, q1, q2;
-    load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * which, q0, q1, q2);
+    load_packed_triangle(sc, which, q0, q1, q2);
     lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
 }
 
@@ -294,7 +299,7 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
         if (state == LT_LEAF && j < t.leaf_count) {
             float4 q0, q1, q2;
             SHRAY_DIAG_T0
-            load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * (t.leaf_first + j), q0, q1, q2);
+            load_packed_triangle(sc, t.leaf_first + j, q0, q1, q2);
             SHRAY_DIAG_WAIT(5);
             lane_test_triangle_loaded<COUNT>(t, t.leaf_first + j, rc, q0, q1, q2);
         }
@@ -397,7 +402,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
         SHRAY_DIAG_COUNT(1);
         if (tri < end) {
             float4 q0, q1, q2;
-            load_packed_triangle(reinterpret_cast<const float4 *>(sc.packed_tris) + 3u * tri, q0, q1, q2);
+            load_packed_triangle(sc, tri, q0, q1, q2);
             if (COUNT)
                 rc.triangle_tests++;
             float d, u, w;

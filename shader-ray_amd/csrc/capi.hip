@@ -415,6 +415,9 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 {
     const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
     const bool latency_launch = frames_in_launch == 1 && spp == 1;
+#ifdef SHRAY_FORCE_LEAF_STAGE   // experiment builds: 0 = always the plain stage, 1 = always the dealt one
+    return SHRAY_FORCE_LEAF_STAGE != 0;
+#endif
     return divergent_scene || latency_launch;
 }
 

@@ -11,6 +11,9 @@
 namespace shray {
 
 constexpr int kBlock = 256;
+// the convergent batch instances (every timed launch) as one-wave workgroups: a wave tile's LDS and wave slot are
+// released when THAT wave ends instead of when the slowest wave of its 16x16 patch does
+constexpr int kBatchBlock = SHRAY_WAVE_BLOCKS ? 64 : 256;
 #ifdef SHRAY_DIAGNOSTICS
 bool g_diag_plain_kernel = false;
 #endif
@@ -52,12 +55,12 @@ static bool metal(const FrameView &fr)
 }
 static bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
 
-template <bool DEAL>
-__device__ __forceinline__ StackTraversal<kBlock, DEAL> make_traversal(uint32_t *lds, int stack_levels, const SceneView &sc)
+template <bool DEAL, int BLOCK = kBlock>
+__device__ __forceinline__ StackTraversal<BLOCK, DEAL> make_traversal(uint32_t *lds, int stack_levels, const SceneView &sc)
 {
-    StackTraversal<kBlock, DEAL> trav;
+    StackTraversal<BLOCK, DEAL> trav;
     trav.stack = lds + threadIdx.x;
-    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * kBlock) + (threadIdx.x & ~63u);
+    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x & ~63u);
 #if SHRAY_LDS_TOP
     // experiment: the workgroup stages the top of the tree (the first SHRAY_LDS_TOP nodes, numbered breadth first
     // by capi.hip under the same flag) behind the stack columns and the id tables
@@ -99,13 +102,13 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
 // DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
 template <bool ONE_SAMPLE, bool METAL, bool DEAL>
-__global__ void __launch_bounds__(kBlock, min_waves(METAL, DEAL)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
-                                                                                          float4 *out, size_t frame_stride, int stack_levels)
+__global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+                                                                                               float4 *out, size_t frame_stride, int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    StackTraversal<kBlock, DEAL> trav = make_traversal<DEAL>(lds_stack, stack_levels, sc);
-    trace_pixels_uniform<StackTraversal<kBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
-                                                                                nullptr, trav);
+    StackTraversal<kBatchBlock, DEAL> trav = make_traversal<DEAL, kBatchBlock>(lds_stack, stack_levels, sc);
+    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y],
+                                                                                     out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
 }
 
 template <bool DIFF>
@@ -117,11 +120,11 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
     trace_pixels<StackTraversal<kBlock, false>, false, DIFF>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
 }
 
-static size_t stack_lds_bytes(int stack_levels)
+static size_t stack_lds_bytes(int stack_levels, int block = kBlock)
 {
     // stack columns + the dealt leaf stage's id tables (64 bytes per wave): 26.25 KB for the 1M-triangle tree
     // (26 levels), which lets six workgroups share a CU's 160 KB
-    return (size_t)kBlock * (size_t)stack_levels * sizeof(uint32_t) + kBlock + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
+    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)block + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
 }
 
 // `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;
@@ -129,8 +132,12 @@ static size_t stack_lds_bytes(int stack_levels)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
 {
-    const dim3 grid(first.total_patches, (unsigned)count), block(kBlock);
-    const size_t lds_bytes = stack_lds_bytes(stack_levels);
+    // the view instances run 256-thread workgroups (a patch each), the convergent ones kBatchBlock-thread workgroups
+    const bool view_instance = !all_plain;
+    const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock);
+    const unsigned int grid_patches = (SHRAY_WAVE_BLOCKS == 2 && !view_instance) ? ((first.total_patches + 7u) & ~7u) : first.total_patches;
+    const dim3 grid(grid_patches * per_patch, (unsigned)count), block(view_instance ? kBlock : kBatchBlock);
+    const size_t lds_bytes = view_instance ? stack_lds_bytes(stack_levels) : stack_lds_bytes(stack_levels, kBatchBlock);
     const bool one = SHRAY_SPECIALIZE && one_sample(first), metallic = SHRAY_SPECIALIZE && all_metal;
 #define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
     if (!all_plain && (first.which == 1 || first.which == 2))

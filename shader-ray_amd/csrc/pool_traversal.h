@@ -46,6 +46,7 @@ constexpr int kPoolMinLevels = 4;           // a column must hold the four resul
 
 template <int BLOCK>
 struct PoolTraversal {
+    static constexpr int block_size = BLOCK;
     uint32_t *stack;    // LDS: levels x BLOCK, column-major ([level][column])
     uint32_t *xbuf;     // LDS: kPoolXbufDwords
     uint32_t *counts;   // LDS: kPoolCountDwords
@@ -61,7 +62,7 @@ struct PoolTraversal {
     {
         const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         LaneTraversal t;
-        lane_begin<COUNT>(sc, t, P, D, rc, has_ray);
+        lane_begin<COUNT>(sc, fr, t, stack + threadIdx.x, P, D, rc, has_ray);
         bool busy = has_ray;            // this lane holds a live ray (its own or an adopted one)
         int state = busy ? LT_WALK : LT_ENDED;
         uint32_t col = threadIdx.x;     // the held ray's stack column = its owner's thread index; travels with the ray
@@ -109,7 +110,7 @@ struct PoolTraversal {
                     slot[1] = make_float4(t.D.y, t.D.z, t.Y.x, t.Y.y);
                     slot[2] = make_float4(t.Y.z, t.YL.x, t.YL.y, t.YL.z);
                     slot[3] = make_float4(t.hit.t, t.hit.which, t.hit.bu, t.hit.bv);
-                    slot[4] = make_float4(__uint_as_float(t.node), __uint_as_float((uint32_t)t.sp), __uint_as_float((uint32_t)t.iter),
+                    slot[4] = make_float4(__uint_as_float(t.node), __uint_as_float((uint32_t)(t.top - (stack + col))), __uint_as_float((uint32_t)t.left),
                                           __uint_as_float(col | (t.divide ? 0x80000000u : 0u)));
                     busy = false;
                     state = LT_ENDED;
@@ -128,10 +129,10 @@ struct PoolTraversal {
                         t.YL = mk(s2.y, s2.z, s2.w);
                         t.hit = Hit{s3.x, s3.y, s3.z, s3.w};
                         t.node = __float_as_uint(s4.x);
-                        t.sp = (int)__float_as_uint(s4.y);
-                        t.iter = (int)__float_as_uint(s4.z);
+                        t.left = (int)__float_as_uint(s4.z);
                         const uint32_t packed = __float_as_uint(s4.w);
                         col = packed & 0x7fffffffu;
+                        t.top = stack + col + __float_as_uint(s4.y);   // the ray's column travels with it; depth in words
                         t.divide = (packed >> 31) != 0u;
                         t.fx = t.D.x >= 0.0f;
                         t.fy = t.D.y >= 0.0f;

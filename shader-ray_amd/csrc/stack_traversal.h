@@ -41,6 +41,7 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 // DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
 template <int BLOCK, bool DEAL = true>
 struct StackTraversal {
+    static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
     uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
     const float4 *top = nullptr;   // LDS copy of the first SHRAY_LDS_TOP packed nodes (experiment, else unused)
@@ -59,7 +60,7 @@ struct StackTraversal {
         if (!traced)
             return 0;
         LaneTraversal t;
-        lane_begin<COUNT>(sc, t, P, D, rc, has_ray);
+        lane_begin<COUNT>(sc, fr, t, stack, P, D, rc, has_ray);
         int state = has_ray ? LT_WALK : LT_ENDED;
         run<COUNT, true>(sc, fr, t, state, rc);
         hit = t.hit;
@@ -71,7 +72,7 @@ struct StackTraversal {
                                             RayCounters &rc)
     {
         LaneTraversal t;
-        lane_begin<COUNT>(sc, t, P, D, rc);
+        lane_begin<COUNT>(sc, fr, t, stack, P, D, rc);
         int state = LT_WALK;
         run<COUNT, false>(sc, fr, t, state, rc);
         hit = t.hit;

@@ -20,6 +20,12 @@
 
 #include "device_types.h"
 
+// 0: the convergent batch instances run 256-thread workgroups (one 16x16 patch); 1: one-wave workgroups (one 8x8 tile),
+// tiles of a patch on consecutive workgroup ids; 2: one-wave workgroups, the four tiles of a patch on one XCD
+#ifndef SHRAY_WAVE_BLOCKS
+#define SHRAY_WAVE_BLOCKS 2
+#endif
+
 namespace shray {
 
 struct V3 {
@@ -374,10 +380,13 @@ __device__ __forceinline__ void add_counters(const RayCounters &rc, DeviceCounte
 
 // Which pixel a thread renders and where it goes: workgroup `patch` is a 16x16 pixel patch (four 8x8 wave
 // tiles) of the whole frame (row-major output) or of the launch's k-th owned tile (packed output).
+// (`wave` = which of the patch's four 8x8 tiles; by default the thread's wave within its 256-thread workgroup)
 __device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int patch, int &px, int &py, size_t &out_index,
-                                             bool &store, bool &inside)
+                                             bool &store, bool &inside, unsigned int wave = 0xffffffffu)
 {
-    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned int lane = threadIdx.x & 63u;
+    if (wave == 0xffffffffu)
+        wave = threadIdx.x >> 6;
     const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
     const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
     store = true;

@@ -23,7 +23,20 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     int px, py;
     size_t out_index;
     bool store, inside;
-    locate_pixel(fr, blockIdx.x, px, py, out_index, store, inside);
+    // a 256-thread workgroup is a 16x16 patch (four 8x8 wave tiles); a 64-thread workgroup is one of those tiles
+    if (Traversal::block_size == 64) {
+#if SHRAY_WAVE_BLOCKS == 2
+        // workgroups go to the eight XCDs round robin: keep the four tiles of a patch on one XCD (one L2), as the
+        // 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus waves leave here.
+        const unsigned int b = blockIdx.x, patch = ((b >> 5) << 3) + (b & 7u);
+        if (patch >= fr.total_patches)
+            return;
+        locate_pixel(fr, patch, px, py, out_index, store, inside, (b >> 3) & 3u);
+#else
+        locate_pixel(fr, blockIdx.x >> 2, px, py, out_index, store, inside, blockIdx.x & 3u);
+#endif
+    } else
+        locate_pixel(fr, blockIdx.x, px, py, out_index, store, inside);
 
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
     const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);

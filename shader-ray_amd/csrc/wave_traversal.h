@@ -68,7 +68,9 @@ struct LaneTraversal {
     uint32_t positive_dir;
     Hit hit;
     uint32_t node;
-    int sp, iter;
+    uint32_t *top;            // LDS: the next free slot of this ray's stack column (slots are BLOCK words apart)
+    int left;                 // node visits left before the iteration cap (fs:426-438), counted down
+    uint32_t leaf_cap;        // fr.max_leaf_tests, held in a scalar register (not re-read from the view at every visit)
     float leaf_r0, leaf_r1;
     uint32_t leaf_first, leaf_count;
 };
@@ -77,8 +79,8 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __bui
 
 // group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
 template <bool COUNT>
-__device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t, V3 P, V3 D, RayCounters &rc,
-                                           bool counted = true)
+__device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack, V3 P, V3 D,
+                                           RayCounters &rc, bool counted = true)
 {
     t.P = P;
     t.D = D;
@@ -92,8 +94,10 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t
     t.positive_dir = (D.x > 0.0f ? 1u : 0u) | (D.y > 0.0f ? 2u : 0u) | (D.z > 0.0f ? 4u : 0u);
     t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
     t.node = sc.packed_root;
-    t.sp = 0;
-    t.iter = 0;
+    t.top = stack;
+    t.left = fr.max_bvh_iterations;
+    t.leaf_cap = (uint32_t)fr.max_leaf_tests;
+    asm volatile("" : "+s"(t.leaf_cap));
     if (COUNT && counted)
         rc.traversals++;
 }
@@ -101,23 +105,22 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, LaneTraversal &t
 // A node visit (with its triangles, if any) is over: follow the link and apply the
 // iteration cap (fs:426-438).  Returns the lane's next state.
 template <int BLOCK>
-__device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, int max_iterations, bool descended,
-                                            uint32_t near_child)
+__device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, bool descended, uint32_t near_child)
 {
     bool finished = false;
     if (descended) {
         t.node = near_child;
-    } else if (t.sp == 0) {
+    } else if (t.top == stack) {
         finished = true;
     } else {
-        t.sp--;
-        t.node = stack[t.sp * BLOCK];
+        t.top -= BLOCK;
+        t.node = *t.top;
     }
-    if (!finished && t.iter == max_iterations - 1) {
+    if (!finished && t.left == 1) {
         t.hit.t = -1.0f;   // set_bad_hit
         finished = true;
     }
-    t.iter++;
+    t.left--;
     return finished ? LT_ENDED : LT_WALK;
 }
 
@@ -151,24 +154,26 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
 
     if (!(r0 >= r1) && (r0 < t.hit.t)) {
         if (b & kLeafFlag) {
-            const uint32_t count = min(b & ~kLeafFlag, (uint32_t)fr.max_leaf_tests);
+            const uint32_t count = min(b & ~kLeafFlag, t.leaf_cap);
             if (count > 0) {
-                t.leaf_first = a;
-                t.leaf_count = count;
-                t.leaf_r0 = r0;
-                t.leaf_r1 = r1;
+                // the parked leaf's four fields are written HERE only.  As plain assignments they become loop-carried
+                // phis that the compiler resolves with eight register copies on the inner-node path (the common one);
+                // a move whose destination is tied to the old value keeps each field in one register on every path.
+                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                             : "+v"(t.leaf_first), "+v"(t.leaf_count), "+v"(t.leaf_r0), "+v"(t.leaf_r1)
+                             : "v"(a), "v"(count), "v"(r0), "v"(r1));
                 return LT_LEAF;
             }
-            return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+            return lane_advance<BLOCK>(t, stack, false, 0u);
         }
         const uint32_t axis = a >> 30;
         const uint32_t pos_child = a & kChildMask, neg_child = b;
         const bool neg_first = (t.positive_dir >> axis) & 1u;
-        stack[t.sp * BLOCK] = neg_first ? pos_child : neg_child;
-        t.sp++;
-        return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, true, neg_first ? neg_child : pos_child);
+        *t.top = neg_first ? pos_child : neg_child;
+        t.top += BLOCK;
+        return lane_advance<BLOCK>(t, stack, true, neg_first ? neg_child : pos_child);
     }
-    return lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+    return lane_advance<BLOCK>(t, stack, false, 0u);
 }
 
 template <bool COUNT, int BLOCK>
@@ -305,7 +310,7 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
         }
     }
     if (state == LT_LEAF)
-        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+        state = lane_advance<BLOCK>(t, stack, false, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -437,7 +442,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
             t.hit.bu = wu;
             t.hit.bv = ww;
         }
-        state = lane_advance<BLOCK>(t, stack, fr.max_bvh_iterations, false, 0u);
+        state = lane_advance<BLOCK>(t, stack, false, 0u);
     }
 }
 

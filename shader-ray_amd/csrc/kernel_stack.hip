@@ -32,6 +32,10 @@ bool g_diag_plain_kernel = false;
 #ifndef SHRAY_MIN_WAVES_DEALT
 #define SHRAY_MIN_WAVES_DEALT 6
 #endif
+// ... and its multi-sample form (the divergent scenes: latency-bound, an extra wave is worth a few spills)
+#ifndef SHRAY_MIN_WAVES_DEALT_MULTI
+#define SHRAY_MIN_WAVES_DEALT_MULTI 7
+#endif
 // the instances with the diffuse / shadow-ray branch carry more state: one wave fewer
 #ifndef SHRAY_MIN_WAVES_GENERAL
 #define SHRAY_MIN_WAVES_GENERAL 5
@@ -74,9 +78,9 @@ __device__ __forceinline__ StackTraversal<BLOCK, DEAL> make_traversal(uint32_t *
     return trav;
 }
 
-constexpr int min_waves(bool metal, bool deal)
+constexpr int min_waves(bool metal, bool deal, bool one_sample = true)
 {
-    return metal ? (deal ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES) : SHRAY_MIN_WAVES_GENERAL;
+    return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES) : SHRAY_MIN_WAVES_GENERAL;
 }
 
 // spp == 1 and a zero diffuse colour get instances without the sample loop / the diffuse branch
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
 // DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
 template <bool ONE_SAMPLE, bool METAL, bool DEAL>
-__global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+__global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
                                                                                                float4 *out, size_t frame_stride, int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];

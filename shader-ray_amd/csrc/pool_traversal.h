@@ -155,11 +155,11 @@ struct PoolTraversal {
 #pragma unroll
                     for (int turn = 0; turn < 2; turn++) {
                         if (state == LT_WALK) {
-                            const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-                            const float4 lo = nodes[2u * t.node];
-                            const float4 hi = nodes[2u * t.node + 1u];
+                            float4 lo, hi;
+                            load_packed_node(sc, t.node, lo, hi);
                             state = lane_visit_loaded<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
                         }
+                        lane_apply_cap(t, state);
                     }
                     turns += 2;
                     const int walking = __popcll(wave_ballot(state == LT_WALK));

@@ -95,33 +95,54 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
     t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
     t.node = sc.packed_root;
     t.top = stack;
-    t.left = fr.max_bvh_iterations;
+    t.left = fr.max_bvh_iterations > 0 ? fr.max_bvh_iterations : -1;   // counted down to the cap; never zero without one
     t.leaf_cap = (uint32_t)fr.max_leaf_tests;
     asm volatile("" : "+s"(t.leaf_cap));
     if (COUNT && counted)
         rc.traversals++;
 }
 
-// A node visit (with its triangles, if any) is over: follow the link and apply the
-// iteration cap (fs:426-438).  Returns the lane's next state.
+// A node visit (with its triangles, if any) is over: follow the link.  Returns the lane's next state; the
+// iteration cap (fs:426-438) is applied by lane_apply_cap, which every caller runs next.
 template <int BLOCK>
 __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, bool descended, uint32_t near_child)
 {
-    bool finished = false;
     if (descended) {
         t.node = near_child;
     } else if (t.top == stack) {
-        finished = true;
+        return LT_ENDED;        // finished: `left` is not counted down (the cap does not apply to a finished ray)
     } else {
         t.top -= BLOCK;
         t.node = *t.top;
     }
-    if (!finished && t.left == 1) {
-        t.hit.t = -1.0f;   // set_bad_hit
-        finished = true;
-    }
     t.left--;
-    return finished ? LT_ENDED : LT_WALK;
+    return LT_WALK;
+}
+
+// The cap of fs:426-438: a ray that has just used its last visit and is not finished becomes a bad hit
+// (set_bad_hit).  `left` reaches zero exactly there (lane_begin starts it at -1 when there is no cap, and it stays
+// zero in a ray that was capped, for which the store below is idempotent), so the test is one comparison per visit
+// and the rare store is skipped by the whole wave -- instead of a compare and two selects in each branch of the visit.
+__device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
+{
+    if (__builtin_expect(__builtin_amdgcn_uicmp((unsigned int)t.left, 0u, 32 /* eq */) != 0ull, 0)) {
+        asm volatile("; iteration cap" ::: "memory");   // keeps this a branch (the compiler would predicate three moves into every visit)
+        if (t.left == 0) {
+            t.hit.t = -1.0f;
+            state = LT_ENDED;
+        }
+    }
+}
+
+// A packed node's two 16-byte words.  The address is the (scalar) base plus a 32-bit byte offset, which the load
+// instruction takes as is (SGPR base + VGPR offset): one shift per visit instead of a 64-bit shift-and-add.
+// (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so node and
+// triangle byte offsets stay far below 2^32.)
+__device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + (node << 5));
+    lo = p[0];
+    hi = p[1];
 }
 
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
@@ -180,9 +201,8 @@ template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack,
                                           RayCounters &rc)
 {
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-    const float4 lo = nodes[2u * t.node];
-    const float4 hi = nodes[2u * t.node + 1u];
+    float4 lo, hi;
+    load_packed_node(sc, t.node, lo, hi);
     return lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
 }
 
@@ -225,7 +245,8 @@ struct PackedF3 {
 };
 __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
 {
-    const PackedF3 *p = reinterpret_cast<const PackedF3 *>(sc.packed_tris) + 3u * index;
+    // base + 32-bit byte offset, as for the nodes
+    const PackedF3 *p = reinterpret_cast<const PackedF3 *>(reinterpret_cast<const char *>(sc.packed_tris) + index * 36u);
     const PackedF3 a = p[0], b = p[1], c = p[2];
     q0 = make_float4(a.x, a.y, a.z, b.x);
     q1 = make_float4(b.y, b.z, c.x, c.y);
@@ -256,9 +277,9 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
         for (int turn = 0; turn < SHRAY_NODE_TURNS; turn++) {   // the exit tests below run once per SHRAY_NODE_TURNS visits
             SHRAY_DIAG_COUNT(0);
             if (state == LT_WALK) {
-                const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
                 SHRAY_DIAG_T0
 #if SHRAY_LDS_TOP
+                const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
                 // experiment (profiles/r02/lds_top_ab.txt): the first SHRAY_LDS_TOP nodes (the top levels, breadth
                 // first) are read from a copy the workgroup staged in LDS
                 float4 lo, hi;
@@ -270,12 +291,13 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                     hi = nodes[2u * t.node + 1u];
                 }
 #else
-                const float4 lo = nodes[2u * t.node];
-                const float4 hi = nodes[2u * t.node + 1u];
+                float4 lo, hi;
+                load_packed_node(sc, t.node, lo, hi);
 #endif
                 SHRAY_DIAG_WAIT(4);
                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
             }
+            lane_apply_cap(t, state);
         }
         const int walking = __popcll(wave_ballot(state == LT_WALK));
         if (walking < keep_walking && (wave_ballot(state == LT_LEAF) || others_waiting))
@@ -311,6 +333,7 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
     }
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, false, 0u);
+    lane_apply_cap(t, state);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -444,6 +467,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
         }
         state = lane_advance<BLOCK>(t, stack, false, 0u);
     }
+    lane_apply_cap(t, state);
 }
 
 }   // namespace shray

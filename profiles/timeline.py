@@ -72,6 +72,13 @@ def main():
     span = t1.max() - start
     dur = (t1 - t0) * 10e-3   # 100 MHz ticks -> microseconds
     print(f"kernel span {span * 10e-3:.1f} us, {len(dur)} waves, {len(np.unique(cu_key))} distinct CUs seen")
+    cyc = (stamps[:, 13] - stamps[:, 12]).astype(np.float64)
+    ticks = (t1 - t0)
+    ok = ticks > 200   # waves resident for more than 2 us
+    if ok.any():
+        ghz = cyc[ok] / ticks[ok] * 0.1
+        print("in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) GHz: p10 %.2f median %.2f p90 %.2f  [SHRAY_DIAG_REPS=%s]"
+              % (*np.percentile(ghz, [10, 50, 90]), os.environ.get("SHRAY_DIAG_REPS", "3")))
     q = np.percentile(dur, [0, 10, 50, 90, 99, 100])
     print("wave duration us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; mean %.1f" % (*q, dur.mean()))
     print(f"sum of wave durations / span = {dur.sum() / (span * 10e-3):.0f} waves resident on average "

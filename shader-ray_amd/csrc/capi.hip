@@ -980,7 +980,11 @@ int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, i
     HIP_TRY(frame.upload(nullptr, (size_t)width * height * 16));
     HIP_TRY(dbg.upload(nullptr, sizeof(DeviceCounters) * kCounterShards + nstamps * 8));
     shray::g_diag_plain_kernel = true;   // stamp the timed (non-counting) kernel
-    for (int rep = 0; rep < 3; rep++) {   // warm caches; the last run's stamps are returned
+    // warm caches; SHRAY_DIAG_REPS back-to-back launches (about 2 s of them) let the clock settle under load before the
+    // in-kernel clock is read from the last run's stamps, which are the ones returned
+    const char *reps_env = getenv("SHRAY_DIAG_REPS");
+    const int reps = reps_env ? std::max(1, atoi(reps_env)) : 3;
+    for (int rep = 0; rep < reps; rep++) {
         rc = launch(scene, fr, (float4 *)frame.p, (DeviceCounters *)dbg.p, nullptr);
         if (rc)
             return rc;

@@ -19,6 +19,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
 #ifdef SHRAY_DIAGNOSTICS
     // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a buffer nothing else reads
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c_begin = __builtin_amdgcn_s_memtime();   // shader cycles: in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
     int px, py;
     size_t out_index;
@@ -140,6 +141,8 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         tl[3] = rc.node_visits;
         for (int k = 0; k < 8; k++)
             tl[4 + k] = pool.diag_tally[k];
+        tl[12] = c_begin;
+        tl[13] = __builtin_amdgcn_s_memtime();
     }
 #endif
     if (COUNT)

@@ -38,6 +38,8 @@ struct Policy {
     int epoch_slack;      // repack only when at least this many lanes would be freed beyond a whole wave
     int interleave;       // 1: wave w of a patch takes the pixels with (x & 1) + 2 (y & 1) == w instead of an 8x8 tile
     int split_heavy;      // > 0: a wave whose stream exceeds this many instructions is replayed as four waves of 16 rays
+    int leaf_cap;         // > 0: the plain leaf stage runs at most this many rounds while rays still walk; a parked ray with
+                          //      triangles left stays parked and resumes in the next leaf stage
 };
 
 struct Ray {
@@ -150,7 +152,8 @@ double traverse(const Costs &c, const Policy &pol, Ray *rays, int n, Totals &t)
                 l = (c.deal_setup + c.deal_finish) * parked + total * c.tri;   // useful work: the tests themselves
                 t.leaf_turns += rounds;
             } else {
-                for (int j = 0; j < maxc; j++) {
+                const int rounds = (pol.leaf_cap > 0 && count(WALK)) ? std::min(maxc, pol.leaf_cap) : maxc;
+                for (int j = 0; j < rounds; j++) {
                     int act = 0;
                     for (int i = 0; i < n; i++)
                         act += state[i] == LEAF && tests[i] > j;
@@ -163,7 +166,20 @@ double traverse(const Costs &c, const Policy &pol, Ray *rays, int n, Totals &t)
                 }
                 w += c.stage_switch;
                 l += c.stage_switch * parked;
-                t.leaf_turns += maxc;
+                t.leaf_turns += rounds;
+                if (rounds < maxc) {   // rays with triangles left stay parked
+                    stream += w;
+                    t.leaf_w += w;
+                    t.leaf_l += l;
+                    for (int i = 0; i < n; i++)
+                        if (state[i] == LEAF) {
+                            if (tests[i] > rounds)
+                                tests[i] -= rounds;
+                            else
+                                state[i] = rays[i].p >= rays[i].end ? ENDED : WALK;
+                        }
+                    continue;
+                }
             }
             stream += w;
             t.leaf_w += w;

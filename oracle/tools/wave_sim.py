@@ -25,7 +25,7 @@ class Costs(C.Structure):
 
 
 class Policy(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("keep_num", "keep_floor", "node_turns", "deal_max_parked", "compact", "deal_group", "async_lanes", "event_min", "pixels_per_wave", "epoch_turns", "epoch_slack", "interleave", "split_heavy")]
+    _fields_ = [(n, C.c_int) for n in ("keep_num", "keep_floor", "node_turns", "deal_max_parked", "compact", "deal_group", "async_lanes", "event_min", "pixels_per_wave", "epoch_turns", "epoch_slack", "interleave", "split_heavy", "leaf_cap")]
 
 
 def run(prefix, costs, policy):
@@ -58,10 +58,10 @@ def report(label, out, ws, gp):
 
 if __name__ == "__main__":
     prefix = sys.argv[1]
-    costs = Costs(gen=90, setup=70, node=95, tri=62, shade=120, env=220, stage_switch=8, loop_iter=10,
+    costs = Costs(gen=90, setup=70, node=64, tri=66, shade=120, env=220, stage_switch=8, loop_iter=10,
                   deal_setup=30, deal_round=85, deal_finish=35, compact=60, event=280)
-    base = dict(keep_num=28, keep_floor=2, node_turns=2, deal_max_parked=0, compact=0, deal_group=0, async_lanes=0, event_min=16, pixels_per_wave=64, epoch_turns=0, epoch_slack=0, interleave=0, split_heavy=0)
-    variants = [("current (keep 28/64, 2 node turns)", {})]
+    base = dict(keep_num=36, keep_floor=2, node_turns=3, deal_max_parked=0, compact=0, deal_group=0, async_lanes=0, event_min=16, pixels_per_wave=64, epoch_turns=0, epoch_slack=0, interleave=0, split_heavy=0, leaf_cap=0)
+    variants = [("current (keep 36/64, 3 node turns)", {})]
     for kn in (16, 40, 48):
         variants.append((f"keep {kn}/64", dict(keep_num=kn)))
     variants += [
@@ -90,6 +90,9 @@ if __name__ == "__main__":
     variants.append(("current, interleaved waves", dict(interleave=1)))
     for thr in (20000, 30000, 40000):
         variants.append((f"dealt always keep 48, heavy waves (> {thr}) split in 4", dict(deal_max_parked=64, keep_num=48, split_heavy=thr)))
+    for cap in (1, 2, 3, 4, 6):
+        variants.append((f"leaf stage capped at {cap} rounds while rays walk", dict(leaf_cap=cap)))
+        variants.append((f"leaf cap {cap}, keep 48/64", dict(leaf_cap=cap, keep_num=48)))
     if os.environ.get("ONLY"):
         variants = [v for v in variants if os.environ["ONLY"] in v[0] or v[0].startswith("current")]
     for label, over in variants:

@@ -323,6 +323,11 @@ struct TreeBuilder {
     }
 };
 
+// 1: multi-sample frames run a pixel's samples in neighbouring lanes (uniform_driver.h); 0: one lane per pixel
+#ifndef SHRAY_SAMPLE_LANES
+#define SHRAY_SAMPLE_LANES 1
+#endif
+
 int validate_params(const shray_frame_params *p, int width, int height, int spp)
 {
     if (!p)
@@ -373,6 +378,17 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     fr->width = width;
     fr->height = height;
     fr->spp = spp;
+    // lanes per pixel of a multi-sample frame (uniform_driver.h): the largest power of two <= min(spp, 64), as a
+    // block of 2^x by 2^y neighbouring lanes of the wave's 8x8 lane grid
+    {
+        int log_g = 0;
+        while (log_g < 6 && (2 << log_g) <= spp)
+            log_g++;
+        if (!SHRAY_SAMPLE_LANES)
+            log_g = 0;
+        fr->sample_log_x = (uint32_t)((log_g + 1) / 2);
+        fr->sample_log_y = (uint32_t)(log_g / 2);
+    }
 
     const bool tiled = tiles && tiles->tile_stride > 0;
     if (!tiled) {
@@ -610,7 +626,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
             }
         }
         s->view.exact_div_ok = coords_ok ? 1u : 0u;
-        s->stack_levels = std::max(1, depth);
+        s->stack_levels = std::max(3, depth);   // at least three: the convergent driver stages a round of samples through levels 0-2
         s->packed_ok = true;
     }
 

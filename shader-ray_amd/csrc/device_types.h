@@ -71,6 +71,9 @@ struct FrameView {
     int32_t patches_x;        // 16x16 patches per row (of the frame, or of one tile)
     int32_t patches_per_unit; // patches per frame / per tile
     uint32_t total_patches;   // grid size in patches
+    // multi-sample frames in the convergent batch kernel: a pixel's samples run in 2^sample_log_x x 2^sample_log_y
+    // neighbouring lanes of a wave (uniform_driver.h); 0, 0 = one lane per pixel
+    uint32_t sample_log_x, sample_log_y;
     const uint32_t *patch_order; // optional: workgroup b renders patch patch_order[b] (a permutation); nullptr = identity
 };
 

@@ -138,7 +138,9 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
 {
     // the view instances run 256-thread workgroups (a patch each), the convergent ones kBatchBlock-thread workgroups
     const bool view_instance = !all_plain;
-    const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock);
+    // one-wave workgroups: four per patch, times the lanes per pixel of a multi-sample frame (uniform_driver.h)
+    const unsigned int sample_lanes = (kBatchBlock == 64 && !one_sample(first)) ? (1u << (first.sample_log_x + first.sample_log_y)) : 1u;
+    const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock) * sample_lanes;
     const unsigned int grid_patches = (SHRAY_WAVE_BLOCKS == 2 && !view_instance) ? ((first.total_patches + 7u) & ~7u) : first.total_patches;
     const dim3 grid(grid_patches * per_patch, (unsigned)count), block(view_instance ? kBlock : kBatchBlock);
     const size_t lds_bytes = view_instance ? stack_lds_bytes(stack_levels) : stack_lds_bytes(stack_levels, kBatchBlock);

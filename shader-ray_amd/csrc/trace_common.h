@@ -378,17 +378,11 @@ __device__ __forceinline__ void add_counters(const RayCounters &rc, DeviceCounte
     }
 }
 
-// Which pixel a thread renders and where it goes: workgroup `patch` is a 16x16 pixel patch (four 8x8 wave
-// tiles) of the whole frame (row-major output) or of the launch's k-th owned tile (packed output).
-// (`wave` = which of the patch's four 8x8 tiles; by default the thread's wave within its 256-thread workgroup)
-__device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int patch, int &px, int &py, size_t &out_index,
-                                             bool &store, bool &inside, unsigned int wave = 0xffffffffu)
+// Pixel (lx, ly) of the 16x16 pixel patch `patch` and where it goes: a patch of the whole frame (row-major output) or
+// of the launch's k-th owned tile (packed output).
+__device__ __forceinline__ void locate_patch_pixel(const FrameView &fr, unsigned int patch, int lx, int ly, int &px, int &py,
+                                                   size_t &out_index, bool &store, bool &inside)
 {
-    const unsigned int lane = threadIdx.x & 63u;
-    if (wave == 0xffffffffu)
-        wave = threadIdx.x >> 6;
-    const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
-    const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
     store = true;
     if (fr.tile_stride == 0) {
         px = (int)(patch % (unsigned int)fr.patches_x) * 16 + lx;
@@ -408,6 +402,19 @@ __device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int p
         out_index = (size_t)k * fr.tile_w * fr.tile_h + (size_t)tly * fr.tile_w + tlx;
     }
     inside = px < fr.width && py < fr.height;
+}
+
+// Which pixel a thread renders: workgroup `patch` is a 16x16 pixel patch = four 8x8 wave tiles.
+// (`wave` = which of the patch's four 8x8 tiles; by default the thread's wave within its 256-thread workgroup)
+__device__ __forceinline__ void locate_pixel(const FrameView &fr, unsigned int patch, int &px, int &py, size_t &out_index,
+                                             bool &store, bool &inside, unsigned int wave = 0xffffffffu)
+{
+    const unsigned int lane = threadIdx.x & 63u;
+    if (wave == 0xffffffffu)
+        wave = threadIdx.x >> 6;
+    const int lx = (int)((wave & 1u) * 8u + (lane & 7u));
+    const int ly = (int)((wave >> 1) * 8u + (lane >> 3));
+    locate_patch_pixel(fr, patch, lx, ly, px, py, out_index, store, inside);
 }
 
 // One thread per pixel; a 256-thread workgroup covers a 16x16 patch as four

@@ -6,6 +6,15 @@
 // those of trace_common.h: trace_ray (same arithmetic, same order); only which == 0 frames come here.
 //
 // Traversal::closest(sc, fr, has_ray, P, D, hit, rc) -> number of rays traced by the group (uniform).
+//
+// Multi-sample frames in one-wave workgroups (SAMPLE LANES): with one lane per pixel a wave runs its 64 pixels' spp
+// samples one after another, so the few heavy waves of a frame (the grazing silhouette) run spp times longer than
+// the others and a lone frame is half tail (profiles/r02/leaf_stage_ab.txt section 22).  Here the G = 2^(x+y) <= 64
+// samples of a pixel run in a block of 2^x by 2^y neighbouring lanes of the wave's 8x8 lane grid: a 16x16 patch is
+// 4 G waves, a wave is 64 / G pixels x G samples -- the heavy pixels' work is spread over G lanes, and the 64 rays
+// of a wave are closer together.  The shader adds a pixel's samples in order (fs:622-636: ((r0 + r1) + r2) + ...);
+// so does this: each round of G samples is staged through the wave's idle stack columns and added, in sample order,
+// by one lane per colour channel.
 #pragma once
 
 #include "trace_common.h"
@@ -24,18 +33,34 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     int px, py;
     size_t out_index;
     bool store, inside;
+    // lanes per pixel (multi-sample frames in one-wave workgroups only): G = gx * gy, this lane runs samples
+    // sub, sub + G, ... of its pixel; base_lane = the pixel's lane with sub == 0
+    const bool sample_lanes = !ONE_SAMPLE && !COUNT && Traversal::block_size == 64;
+    const unsigned int log_gx = sample_lanes ? fr.sample_log_x : 0u, log_gy = sample_lanes ? fr.sample_log_y : 0u;
+    const unsigned int G = 1u << (log_gx + log_gy);
+    unsigned int sub = 0, base_lane = threadIdx.x & 63u;
     // a 256-thread workgroup is a 16x16 patch (four 8x8 wave tiles); a 64-thread workgroup is one of those tiles
     if (Traversal::block_size == 64) {
 #if SHRAY_WAVE_BLOCKS == 2
-        // workgroups go to the eight XCDs round robin: keep the four tiles of a patch on one XCD (one L2), as the
-        // 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus waves leave here.
-        const unsigned int b = blockIdx.x, patch = ((b >> 5) << 3) + (b & 7u);
+        // workgroups go to the eight XCDs round robin: keep the waves of a patch (four, or 4 G with sample lanes) on one
+        // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
+        // waves leave here.
+        const unsigned int log_waves = 2u + log_gx + log_gy;
+        const unsigned int b = blockIdx.x, k = b >> 3, patch = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
         if (patch >= fr.total_patches)
             return;
-        locate_pixel(fr, patch, px, py, out_index, store, inside, (b >> 3) & 3u);
 #else
-        locate_pixel(fr, blockIdx.x >> 2, px, py, out_index, store, inside, blockIdx.x & 3u);
+        const unsigned int log_waves = 2u + log_gx + log_gy;
+        const unsigned int patch = blockIdx.x >> log_waves, wave = blockIdx.x & ((1u << log_waves) - 1u);
 #endif
+        // the patch as (16 gx) x (16 gy) lane positions, cut into 8x8 wave tiles: position (vx, vy) is sample
+        // (vy % gy) * gx + vx % gx of pixel (vx / gx, vy / gy)
+        const unsigned int lane = threadIdx.x, tiles_across = 2u << log_gx;
+        const unsigned int vx = (wave & (tiles_across - 1u)) * 8u + (lane & 7u), vy = (wave >> (1u + log_gx)) * 8u + (lane >> 3);
+        const unsigned int sx = vx & ((1u << log_gx) - 1u), sy = vy & ((1u << log_gy) - 1u);
+        sub = (sy << log_gx) | sx;
+        base_lane = lane - (sy * 8u + sx);
+        locate_patch_pixel(fr, patch, (int)(vx >> log_gx), (int)(vy >> log_gy), px, py, out_index, store, inside);
     } else
         locate_pixel(fr, blockIdx.x, px, py, out_index, store, inside);
 
@@ -48,7 +73,10 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     const int samples = ONE_SAMPLE ? 1 : fr.spp;
 
     V3 sum = mk(0, 0, 0);
-    for (int s = 0; s < samples; s++) {
+    float channel_sum = 0.0f, channel_sum2 = 0.0f;   // sample lanes: this lane's colour channel (lane 0 of a pair: also blue)
+    for (int s0 = 0; s0 < samples; s0 += (int)G) {
+        const int s = s0 + (int)sub;
+        const bool has_sample = inside && s < samples;
         // primary ray (vs:39-60, fs:619), sub-pixel pattern of the oracle
         const float ox = ((float)s + 0.5f) / fn;
         const float oy = (float)__brev((unsigned int)s) * 2.3283064365386963e-10f + 0.5f / fn;
@@ -59,7 +87,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
 
         V3 accumulated = mk(0, 0, 0), modulation = mk(1, 1, 1);
-        bool alive = inside;      // still inside trace()'s bounce loop
+        bool alive = has_sample;  // still inside trace()'s bounce loop
         bool marker = false;      // returned the bad-hit colour (fs:566-568): no environment term
         for (int bounce = 0; bounce < fr.bounce_count; bounce++) {
             Hit hit{kFar, -1.0f, 0.0f, 0.0f};
@@ -117,18 +145,57 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             }
         }
         V3 radiance = mk(1.0f, 0.0f, 0.0f);
-        if (inside && !marker) {
+        if (has_sample && !marker) {
             if (COUNT)
                 rc.env_lookups++;
             radiance = accumulated + modulation * environment(sc, D);
         }
-        sum = (ONE_SAMPLE || fr.spp == 1) ? radiance : sum + radiance;
+        if (G == 1u) {
+            sum = (ONE_SAMPLE || fr.spp == 1) ? radiance : sum + radiance;
+        } else {
+            // this round's G radiances of every pixel, through levels 0-2 of the wave's stack columns (the stacks are
+            // empty between traversals), then added in sample order: lane `sub` of a pixel sums channel `sub`
+            // (of a pair of lanes, lane 0 sums red and blue); the other lanes of the pixel add along, unused
+            uint32_t *lds = pool.stack - threadIdx.x;
+            lds[threadIdx.x] = __float_as_uint(radiance.x);
+            lds[64u + threadIdx.x] = __float_as_uint(radiance.y);
+            lds[128u + threadIdx.x] = __float_as_uint(radiance.z);
+            __syncthreads();   // one wave: orders the exchange for the compiler, costs nothing
+            const unsigned int channel = sub < 3u ? sub : 2u;
+            const int valid = min((int)G, samples - s0);
+            for (int k = 0; k < valid; k++) {
+                const unsigned int src = base_lane + (((unsigned int)k >> log_gx) << 3) + ((unsigned int)k & ((1u << log_gx) - 1u));
+                channel_sum = channel_sum + __uint_as_float(lds[channel * 64u + src]);
+                if (G == 2u)
+                    channel_sum2 = channel_sum2 + __uint_as_float(lds[128u + src]);
+            }
+            __syncthreads();
+        }
     }
-    V3 result = (ONE_SAMPLE || fr.spp == 1) ? sum : sum / fn;
-    if (fr.tonemap)
-        result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
-    if (store)
-        out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+    if (G > 1u) {
+        // sum / n and the tone map are per channel (fs:636-640); the pixel's first lane collects the three and stores
+        float c0 = channel_sum / fn, c2 = channel_sum2 / fn;
+        if (fr.tonemap) {
+            c0 = filmic(c0);
+            c2 = filmic(c2);
+        }
+        uint32_t *lds = pool.stack - threadIdx.x;
+        if (sub < 3u)
+            lds[sub * 64u + base_lane] = __float_as_uint(c0);
+        if (G == 2u && sub == 0u)
+            lds[128u + base_lane] = __float_as_uint(c2);
+        __syncthreads();
+        if (sub == 0u && store)
+            out[out_index] = inside ? make_float4(__uint_as_float(lds[threadIdx.x]), __uint_as_float(lds[64u + threadIdx.x]),
+                                                  __uint_as_float(lds[128u + threadIdx.x]), 1.0f)
+                                    : make_float4(0, 0, 0, 0);
+    } else {
+        V3 result = (ONE_SAMPLE || fr.spp == 1) ? sum : sum / fn;
+        if (fr.tonemap)
+            result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
+        if (store)
+            out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+    }
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && (threadIdx.x & 63u) == 0) {
         unsigned long long *tl = reinterpret_cast<unsigned long long *>(counters + kCounterShards) + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));

@@ -41,6 +41,14 @@ bool g_diag_plain_kernel = false;
 #define SHRAY_MIN_WAVES_GENERAL 5
 #endif
 // launch the spp == 1 / metal instances of the plain kernel where they apply
+// the diffuse / shadow-ray instances follow the leaf-stage policy too: on cache-resident scenes the plain leaf loop,
+// which fits six waves per SIMD (plaster 8 spp 2.57 -> 2.42 ms, profiles/r02/leaf_stage_ab.txt section 22)
+#ifndef SHRAY_GENERAL_PLAIN
+#define SHRAY_GENERAL_PLAIN 1
+#endif
+#ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN
+#define SHRAY_MIN_WAVES_GENERAL_PLAIN 6
+#endif
 #ifndef SHRAY_SPECIALIZE
 #define SHRAY_SPECIALIZE 1
 #endif
@@ -80,7 +88,8 @@ __device__ __forceinline__ StackTraversal<BLOCK, DEAL> make_traversal(uint32_t *
 
 constexpr int min_waves(bool metal, bool deal, bool one_sample = true)
 {
-    return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES) : SHRAY_MIN_WAVES_GENERAL;
+    return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES)
+                 : (deal ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_PLAIN);
 }
 
 // spp == 1 and a zero diffuse colour get instances without the sample loop / the diffuse branch
@@ -150,12 +159,17 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
         SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<true>);
     else if (!all_plain)
         SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<false>);
-    // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of the gold-class instances; the
-    // instances with the diffuse branch run at five waves per SIMD either way and always deal
+    // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of each class of instances
     else if (one && metallic && deal)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, true>));
     else if (one && metallic)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, false>));
+#if SHRAY_GENERAL_PLAIN
+    else if (one && !deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, false, false>));
+    else if (!one && !metallic && !deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<false, false, false>));
+#endif
     else if (one)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, false, true>));
     else if (metallic && deal)

@@ -603,3 +603,39 @@ def test_config5_4k_16spp_eight_way_tile_split(pkg, gpu, bunny):
     frame = assemble_tiles_torch(gathered.view(ranks, per_rank, tile, tile, 4), W, H, tile, tile)
     torch.cuda.synchronize()
     assert torch.equal(frame.reshape(-1), full)
+
+
+@pytest.mark.parametrize("material", [0, 6])
+def test_sample_lanes_every_group_size(pkg, gpu, oracle_mod, bunny, env_sky, material):
+    """Multi-sample frames run a pixel's samples in G = 2, 4, ... 64 neighbouring lanes of a wave and add them in sample
+    order (uniform_driver.h).  Every group size, sample counts that do not fill the last round, a frame whose edges cut
+    through patches, whole frames and tile sets: bit-identical to the oracle (raytracer.es.fs:622-640)."""
+    world, desc, scene = bunny
+    scene.set_kernel(0)
+    W, H = 45, 27
+    params = world.frame_params(W, H, material=material)
+    for spp in (2, 3, 4, 5, 8, 13, 16, 32, 64, 100):
+        want, _ = oracle_mod.render(desc, env_sky, params, W, H, spp)
+        got = scene.render(params, W, H, spp)
+        differing = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert differing == 0, f"{spp} spp, material {material}: {differing} floats differ from the oracle"
+    # tile sets at 4 and 64 spp: the owned tiles of three uneven sets reassemble to the whole frame
+    import torch
+    W, H = 96, 64
+    params = world.frame_params(W, H, material=material)
+    for spp in (4, 64):
+        whole = scene.render(params, W, H, spp)
+        frame = np.zeros_like(whole)
+        for phase, count in ((0, 1), (1, 2), (3, 1)):
+            tiles = pkg._native.TileSet(32, 32, 4, phase, count)
+            nbytes = pkg.tracer.tile_buffer_bytes(W, H, tiles)
+            buf = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+            scene.render_into(params, W, H, spp, buf.data_ptr(), torch.cuda.current_stream().cuda_stream, tiles)
+            torch.cuda.synchronize()
+            packed = buf.cpu().numpy().reshape(-1, 32, 32, 4)
+            owned = [t for t in range((W // 32) * (H // 32)) if phase <= t % 4 < phase + count]
+            assert len(owned) == packed.shape[0]
+            for k, t in enumerate(owned):
+                ty, tx = divmod(t, W // 32)
+                frame[ty * 32:(ty + 1) * 32, tx * 32:(tx + 1) * 32] = packed[k]
+        assert np.array_equal(frame.view(np.uint32), whole.view(np.uint32)), f"tile sets at {spp} spp"

@@ -32,9 +32,10 @@ bool g_diag_plain_kernel = false;
 #ifndef SHRAY_MIN_WAVES_DEALT
 #define SHRAY_MIN_WAVES_DEALT 6
 #endif
-// ... and its multi-sample form (the divergent scenes: latency-bound, an extra wave is worth a few spills)
+// ... and its multi-sample form (the divergent scenes: latency-bound, every extra wave is worth its spills: the
+// 1M-triangle scene at 4 spp 3.10 / 2.96 / 2.85 ms at 6 / 7 / 8 waves per SIMD, profiles/r02/leaf_stage_ab.txt section 22)
 #ifndef SHRAY_MIN_WAVES_DEALT_MULTI
-#define SHRAY_MIN_WAVES_DEALT_MULTI 7
+#define SHRAY_MIN_WAVES_DEALT_MULTI 8
 #endif
 // the instances with the diffuse / shadow-ray branch carry more state: one wave fewer
 #ifndef SHRAY_MIN_WAVES_GENERAL

@@ -195,7 +195,7 @@ def test_shader_constants_as_parameters(pkg, gpu, oracle_mod, material):
     W, H = 120, 72
     variants = [dict(bounce_count=0), dict(bounce_count=2), dict(max_leaf_tests=3), dict(max_leaf_tests=0),
                 dict(max_bvh_iterations=12), dict(cast_shadows=0, bounce_count=5), dict(tonemap=0)]
-    for spp in (1, 2):
+    for spp in (1, 2, 7):   # 2 and 7: sample lanes in pairs and in fours, the last round not full (uniform_driver.h)
         for overrides in variants:
             params = world.frame_params(W, H, material=material)
             for key, value in overrides.items():

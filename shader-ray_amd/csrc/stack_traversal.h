@@ -52,7 +52,11 @@ struct StackTraversal {
     // Convergent form (uniform_driver.h): all 64 lanes of the wave call it together; has_ray = this lane's pixel
     // has a ray to trace.  Lanes without one take part in the dealt leaf stage as workers.  Returns the number
     // of rays the wave traced.
-    template <bool COUNT>
+    // ANY_HIT (shadow rays of the timed kernels, uniform_driver.h): the caller only asks whether hit.t stays at
+    // "infinitely far" (fs:516-521: lit = shadow.t >= far).  Once a leaf has produced a hit the answer is "no" whatever
+    // the rest of the walk finds -- a closer hit, or the iteration cap's bad hit (t = -1) -- so the ray stops there.
+    // The counting twins walk on: their tallies are compared with the reference's full traversal.
+    template <bool COUNT, bool ANY_HIT = false>
     __device__ __forceinline__ int closest(const SceneView &sc, const FrameView &fr, bool has_ray, V3 P, V3 D, Hit &hit,
                                            RayCounters &rc)
     {
@@ -62,7 +66,7 @@ struct StackTraversal {
         LaneTraversal t;
         lane_begin<COUNT>(sc, fr, t, stack, P, D, rc, has_ray);
         int state = has_ray ? LT_WALK : LT_ENDED;
-        run<COUNT, true>(sc, fr, t, state, rc);
+        run<COUNT, true, ANY_HIT && !COUNT>(sc, fr, t, state, rc);
         hit = t.hit;
         return traced;
     }
@@ -79,7 +83,7 @@ struct StackTraversal {
     }
 
     // CONVERGED: every lane of the wave is executing (the dealt leaf stage may use them all)
-    template <bool COUNT, bool CONVERGED>
+    template <bool COUNT, bool CONVERGED, bool ANY_HIT = false>
     __device__ __forceinline__ void run(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state, RayCounters &rc)
     {
         do {
@@ -101,6 +105,8 @@ struct StackTraversal {
                 leaf_stage_dealt<COUNT, BLOCK>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             else
                 leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
+            if (ANY_HIT && state != LT_ENDED && t.hit.t < kFar)
+                state = LT_ENDED;   // a hit: the shadow query is answered (a capped ray, t = -1, has ended already)
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c2 = __builtin_amdgcn_s_memtime();
             diag_tally[2] += c1 - c0;

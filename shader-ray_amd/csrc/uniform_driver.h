@@ -21,6 +21,11 @@
 
 namespace shray {
 
+// shadow rays stop at their first hit (stack_traversal.h: closest<COUNT, ANY_HIT>); 0 = walk them to the end
+#ifndef SHRAY_SHADOW_ANY_HIT
+#define SHRAY_SHADOW_ANY_HIT 1
+#endif
+
 template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool)
@@ -126,7 +131,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                 bool lit = true;
                 if (fr.cast_shadows) {                            // uniform
                     Hit shadow{kFar, -1.0f, 0.0f, 0.0f};
-                    pool.template closest<COUNT>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
+                    pool.template closest<COUNT, SHRAY_SHADOW_ANY_HIT != 0>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
                                                  xform(fr.object_normal_matrix, light, 0.0f), shadow, rc);
                     lit = shadow.t >= kFar;
                 }

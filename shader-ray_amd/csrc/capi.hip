@@ -418,15 +418,16 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     return SHRAY_OK;
 }
 
-// Which leaf stage the gold-class (zero diffuse colour) instances of the stack kernel run.  Dealing a parked
-// ray's triangles to the wave's idle lanes shortens divergent waves -- fewer instructions, one memory round
-// trip per leaf instead of up to ten -- but the instance holds a second ray's worth of registers: six waves per
-// SIMD instead of seven.  Measured on MI355X (profiles/r02/leaf_stage_ab.txt):
+// Which leaf stage the convergent instances of the stack kernel run.  Dealing a parked ray's triangles to the
+// wave's idle lanes shortens divergent waves -- fewer instructions, one memory round trip per leaf instead of up
+// to ten -- but the instance holds a second ray's worth of registers: six waves per SIMD instead of eight for the
+// spp == 1 gold instance, five instead of six for the diffuse / shadow-ray ones.  Measured on MI355X
+// (profiles/r02/leaf_stage_ab.txt):
 //   * trees larger than an XCD's L2 share (the 1M-triangle scene, 9.4 MB of nodes): rays diverge, the walk is
 //     latency-bound, dealing wins by 10-18 %;
 //   * one spp == 1 frame per launch (latency): the frame ends with a tail of divergent waves, dealing wins by 11 %;
 //   * a cache-resident scene rendered for throughput (several frames per launch, or many samples per pixel):
-//     the GPU is full of coherent waves, the seventh wave is worth more (5 %).
+//     the GPU is full of coherent waves, the extra waves are worth more (3-6 %).
 bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 {
     const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);

@@ -1,9 +1,8 @@
 // kernel_stack.hip -- kernel id 0: per-ray LDS stack over the packed BVH (stack_traversal.h).
 //
-// LDS: BLOCK * stack_levels * 4 bytes of dynamic shared memory; stack_levels
-// is the tree's depth (computed at scene creation), so the bunny-class tree
-// (depth 20) costs 20 KB per 256-thread workgroup and leaves room for 8
-// workgroups (32 waves) per CU.
+// LDS: BLOCK * stack_levels * 4 bytes of dynamic shared memory (+ 64 bytes per wave for the dealt leaf stage);
+// stack_levels is the deepest stack the tree can ask for (computed at scene creation): 3.9 KB per wave for the
+// bunny-class tree (15 levels), 6.6 KB for the 1M-triangle tree (26 levels: 24 waves per CU).
 #include "launch.h"
 #include "stack_traversal.h"
 #include "uniform_driver.h"
@@ -18,12 +17,10 @@ constexpr int kBatchBlock = SHRAY_WAVE_BLOCKS ? 64 : 256;
 bool g_diag_plain_kernel = false;
 #endif
 
-// Waves per SIMD the register allocator must leave room for.  Left alone, the plain kernel sits at the
-// 128-register boundary (arch VGPRs + the AGPRs that hold spilled SGPRs): a few registers more and only
-// three waves fit.  Asking for six (<= 85 registers) spills more to scratch and wins it back with
-// occupancy -- with the plain one-triangle / one-visit loops of wave_traversal.h, which need fewer
-// registers: one frame 0.58 -> 0.558 ms, pipelined 0.389 -> 0.357 ms, 1M-triangle scene 2.04 -> 1.77 ms.
-// Seven and eight lose again on the benchmark frame (profiles/ab_sweep.sh).
+// Waves per SIMD the register allocator must leave room for (measured per instance, profiles/r02/leaf_stage_ab.txt):
+// the plain gold instances are asked for seven (<= 72 registers); the spp == 1 one needs 63 since the library is
+// built without the SLP vectoriser and runs eight, the multi-sample one 72 with its spills outside the loops
+// (forced to eight it is slower).
 #ifndef SHRAY_MIN_WAVES
 #define SHRAY_MIN_WAVES 7
 #endif
@@ -41,7 +38,6 @@ bool g_diag_plain_kernel = false;
 #ifndef SHRAY_MIN_WAVES_GENERAL
 #define SHRAY_MIN_WAVES_GENERAL 5
 #endif
-// launch the spp == 1 / metal instances of the plain kernel where they apply
 // the diffuse / shadow-ray instances follow the leaf-stage policy too: on cache-resident scenes the plain leaf loop,
 // which fits six waves per SIMD (plaster 8 spp 2.57 -> 2.42 ms, profiles/r02/leaf_stage_ab.txt section 22)
 #ifndef SHRAY_GENERAL_PLAIN
@@ -50,6 +46,7 @@ bool g_diag_plain_kernel = false;
 #ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN
 #define SHRAY_MIN_WAVES_GENERAL_PLAIN 6
 #endif
+// launch the spp == 1 / metal instances of the plain kernel where they apply
 #ifndef SHRAY_SPECIALIZE
 #define SHRAY_SPECIALIZE 1
 #endif
@@ -136,13 +133,12 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 
 static size_t stack_lds_bytes(int stack_levels, int block = kBlock)
 {
-    // stack columns + the dealt leaf stage's id tables (64 bytes per wave): 26.25 KB for the 1M-triangle tree
-    // (26 levels), which lets six workgroups share a CU's 160 KB
+    // stack columns + the dealt leaf stage's id tables (64 bytes per wave)
     return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)block + SHRAY_LDS_PAD + (size_t)SHRAY_LDS_TOP * 32;
 }
 
 // `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;
-// `deal`: the gold-class instances use the dealt leaf stage (six waves per SIMD) instead of the plain one (seven)
+// `deal`: the dealt leaf stage instead of the plain one (capi.hip: leaf_stage_policy)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
 {

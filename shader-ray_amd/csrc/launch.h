@@ -21,9 +21,8 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 // `count` frames in one launch (grid.y = frame): d_frames[k] is frame k's view, written to
 // out + k * frame_stride (in float4 units); `first` is frame 0's view (grid shape, differential class)
 // all_metal: every frame's diffuse colour is zero (selects the kernel instance without the diffuse branch)
-// all_plain: every frame is a plain which == 0 frame (the convergent driver applies); deal: the gold-class
-// instances deal leaf triangles to idle lanes (wave_traversal.h) at six waves per SIMD instead of the plain
-// leaf loop at seven
+// all_plain: every frame is a plain which == 0 frame (the convergent driver applies); deal: the instances that deal
+// leaf triangles to idle lanes (wave_traversal.h) instead of the plain leaf loop
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
 

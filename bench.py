@@ -338,12 +338,15 @@ def main():
         result["roofline"] = roof
         result["counters"] = counters
         # the C ABI's host-buffer forms, PCIe-inclusive, for the record (never `value`): the blocking call into
-        # pageable memory (staged through pinned pieces) and the stream form into pinned memory, double-buffered
+        # pageable memory (the runtime's staged copy, into a buffer the loop reuses) and the stream form into pinned memory, double-buffered
         from shader_ray_amd.tracer import PinnedFrame
+        import numpy as np
+        host_frame = np.empty((HEIGHT, WIDTH, 4), dtype=np.float32)   # a frame loop's own (pageable) buffer, reused
+        scene.render(params, WIDTH, HEIGHT, SPP, out=host_frame)      # first touch of its pages
         t0 = time.perf_counter()
-        for _ in range(5):
-            scene.render(params, WIDTH, HEIGHT, SPP)
-        result["host_readback_mrays"] = round(WIDTH * HEIGHT * SPP * 5 / (time.perf_counter() - t0) / 1e6, 2)
+        for _ in range(10):
+            scene.render(params, WIDTH, HEIGHT, SPP, out=host_frame)
+        result["host_readback_mrays"] = round(WIDTH * HEIGHT * SPP * 10 / (time.perf_counter() - t0) / 1e6, 2)
         pinned = [PinnedFrame(WIDTH, HEIGHT) for _ in range(2)]
         scene2 = pkg.Scene(desc, env, device=local_rank)   # one in-flight readback per scene: two scenes double-buffer
         pair = [scene, scene2]

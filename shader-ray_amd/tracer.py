@@ -49,9 +49,13 @@ class Scene:
     def set_kernel(self, kernel_id: int):
         N.check(self._lib.shray_scene_set_kernel(self._handle, kernel_id))
 
-    def render(self, params: N.FrameParams, width: int, height: int, spp: int = 1) -> np.ndarray:
-        """Blocking render to host memory: RGBA float32 [height, width, 4], row 0 = bottom."""
-        out = np.empty((height, width, 4), dtype=np.float32)
+    def render(self, params: N.FrameParams, width: int, height: int, spp: int = 1, out: np.ndarray | None = None) -> np.ndarray:
+        """Blocking render to host memory: RGBA float32 [height, width, 4], row 0 = bottom.  `out`: a C-contiguous
+        float32 array of that shape to fill (a frame loop reuses one: a fresh 33 MB array costs its page faults)."""
+        if out is None:
+            out = np.empty((height, width, 4), dtype=np.float32)
+        elif out.shape != (height, width, 4) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape (height, width, 4)")
         N.check(self._lib.shray_render(self._handle, C.byref(params), width, height, spp,
                                        out.ctypes.data_as(N.c_float_p)))
         return out

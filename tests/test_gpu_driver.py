@@ -77,7 +77,7 @@ def test_animation_driver_frames_and_histogram(pkg, gpu, tmp_path):
 
 
 def test_readback_forms_return_the_device_frame(pkg, gpu):
-    """shray_render into pageable memory (staged in pieces), into pinned memory (one DMA) and
+    """shray_render into pageable memory (fresh and reused buffers), into pinned memory (one DMA) and
     shray_render_host_async all deliver the frame shray_render_device leaves on the GPU; the
     scene's frame buffer is reused across sizes."""
     import torch
@@ -92,6 +92,10 @@ def test_readback_forms_return_the_device_frame(pkg, gpu):
         torch.cuda.synchronize()
         want = dev.cpu().numpy()
         assert np.array_equal(scene.render(params, W, H, spp), want)
+        mine = np.full((H, W, 4), -1.0, dtype=np.float32)      # a frame loop's own buffer, filled in place
+        assert scene.render(params, W, H, spp, out=mine) is mine and np.array_equal(mine, want)
+        with pytest.raises(ValueError):
+            scene.render(params, W, H, spp, out=np.empty((H, W, 3), dtype=np.float32))
         pinned = PinnedFrame(W, H)
         pinned.array[:] = -1.0
         got = scene.render_to_pinned(params, W, H, spp, pinned, stream, wait=True)

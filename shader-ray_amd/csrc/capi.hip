@@ -327,6 +327,10 @@ struct TreeBuilder {
 #ifndef SHRAY_SAMPLE_LANES
 #define SHRAY_SAMPLE_LANES 1
 #endif
+// at most 2^5 = 32 lanes per pixel: plaster 64 spp 16.38 / 15.83 / 16.26 ms with up to 64 / 32 / 16 (profiles/sample_lanes_probe.sh)
+#ifndef SHRAY_SAMPLE_LANES_LOG2_MAX
+#define SHRAY_SAMPLE_LANES_LOG2_MAX 5
+#endif
 
 int validate_params(const shray_frame_params *p, int width, int height, int spp)
 {
@@ -378,11 +382,11 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
     fr->width = width;
     fr->height = height;
     fr->spp = spp;
-    // lanes per pixel of a multi-sample frame (uniform_driver.h): the largest power of two <= min(spp, 64), as a
+    // lanes per pixel of a multi-sample frame (uniform_driver.h): the largest power of two <= min(spp, 32), as a
     // block of 2^x by 2^y neighbouring lanes of the wave's 8x8 lane grid
     {
         int log_g = 0;
-        while (log_g < 6 && (2 << log_g) <= spp)
+        while (log_g < SHRAY_SAMPLE_LANES_LOG2_MAX && (2 << log_g) <= spp)
             log_g++;
         if (!SHRAY_SAMPLE_LANES)
             log_g = 0;

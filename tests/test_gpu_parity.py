@@ -607,7 +607,7 @@ def test_config5_4k_16spp_eight_way_tile_split(pkg, gpu, bunny):
 
 @pytest.mark.parametrize("material", [0, 6])
 def test_sample_lanes_every_group_size(pkg, gpu, oracle_mod, bunny, env_sky, material):
-    """Multi-sample frames run a pixel's samples in G = 2, 4, ... 64 neighbouring lanes of a wave and add them in sample
+    """Multi-sample frames run a pixel's samples in G = 2, 4, ... 32 neighbouring lanes of a wave (in rounds beyond that) and add them in sample
     order (uniform_driver.h).  Every group size, sample counts that do not fill the last round, a frame whose edges cut
     through patches, whole frames and tile sets: bit-identical to the oracle (raytracer.es.fs:622-640)."""
     world, desc, scene = bunny

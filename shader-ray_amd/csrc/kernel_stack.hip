@@ -47,6 +47,10 @@ bool g_diag_plain_kernel = false;
 #define SHRAY_MIN_WAVES_GENERAL_PLAIN 6
 #endif
 // launch the spp == 1 / metal instances of the plain kernel where they apply
+// the frames of a launch interleaved along grid.x instead of stacked on grid.y (convergent instances)
+#ifndef SHRAY_INTERLEAVE_FRAMES
+#define SHRAY_INTERLEAVE_FRAMES 1
+#endif
 #ifndef SHRAY_SPECIALIZE
 #define SHRAY_SPECIALIZE 1
 #endif
@@ -114,12 +118,30 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
 template <bool ONE_SAMPLE, bool METAL, bool DEAL>
 __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
-                                                                                               float4 *out, size_t frame_stride, int stack_levels)
+                                                                                               float4 *out, size_t frame_stride, int stack_levels,
+                                                                                               int frame_count_arg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     StackTraversal<kBatchBlock, DEAL> trav = make_traversal<DEAL, kBatchBlock>(lds_stack, stack_levels, sc);
+#if SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES
+    // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
+    // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
+    // start when the launch is half over (what a lone launch, or the last of a run, then waits for)
+    const unsigned int frame_count = gridDim.y == 1 ? (unsigned int)frame_count_arg : 1u;
+    unsigned int frame = blockIdx.y, block_index = blockIdx.x;
+    if (frame_count > 1u) {
+        const FrameView &f0 = frames[0];
+        const unsigned int log_waves = 2u + (ONE_SAMPLE ? 0u : f0.sample_log_x + f0.sample_log_y);
+        const unsigned int b = blockIdx.x, k = b >> 3, rest = k >> log_waves;
+        frame = rest % frame_count;
+        block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
+    }
+    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[frame], out + (size_t)frame * frame_stride,
+                                                                                     nullptr, trav, block_index);
+#else
     trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y],
                                                                                      out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
+#endif
 }
 
 template <bool DIFF>
@@ -148,14 +170,18 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     const unsigned int sample_lanes = (kBatchBlock == 64 && !one_sample(first)) ? (1u << (first.sample_log_x + first.sample_log_y)) : 1u;
     const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock) * sample_lanes;
     const unsigned int grid_patches = (SHRAY_WAVE_BLOCKS == 2 && !view_instance) ? ((first.total_patches + 7u) & ~7u) : first.total_patches;
-    const dim3 grid(grid_patches * per_patch, (unsigned)count), block(view_instance ? kBlock : kBatchBlock);
+    // convergent instances: the frames of the launch interleaved along grid.x (see the kernel); the view instances keep grid.y = frame
+    const bool interleave = SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES && !view_instance && count > 1;
+    const dim3 grid(grid_patches * per_patch * (interleave ? (unsigned)count : 1u), interleave ? 1u : (unsigned)count),
+        block(view_instance ? kBlock : kBatchBlock);
     const size_t lds_bytes = view_instance ? stack_lds_bytes(stack_levels) : stack_lds_bytes(stack_levels, kBatchBlock);
     const bool one = SHRAY_SPECIALIZE && one_sample(first), metallic = SHRAY_SPECIALIZE && all_metal;
-#define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
+#define SHRAY_LAUNCH_VIEW_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
+#define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels, count)
     if (!all_plain && (first.which == 1 || first.which == 2))
-        SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<true>);
+        SHRAY_LAUNCH_VIEW_BATCH(trace_stack_view_batch_kernel<true>);
     else if (!all_plain)
-        SHRAY_LAUNCH_BATCH(trace_stack_view_batch_kernel<false>);
+        SHRAY_LAUNCH_VIEW_BATCH(trace_stack_view_batch_kernel<false>);
     // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of each class of instances
     else if (one && metallic && deal)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, true>));
@@ -176,6 +202,7 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     else
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<false, false, true>));
 #undef SHRAY_LAUNCH_BATCH
+#undef SHRAY_LAUNCH_VIEW_BATCH
     return hipGetLastError();
 }
 

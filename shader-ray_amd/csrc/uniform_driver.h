@@ -28,8 +28,11 @@ namespace shray {
 
 template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
-                                                     DeviceCounters *counters, Traversal &pool)
+                                                     DeviceCounters *counters, Traversal &pool,
+                                                     unsigned int block_index = 0xffffffffu)   // default: blockIdx.x
 {
+    if (block_index == 0xffffffffu)
+        block_index = blockIdx.x;
 #ifdef SHRAY_DIAGNOSTICS
     // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a buffer nothing else reads
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
@@ -51,12 +54,12 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
         // waves leave here.
         const unsigned int log_waves = 2u + log_gx + log_gy;
-        const unsigned int b = blockIdx.x, k = b >> 3, patch = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
+        const unsigned int b = block_index, k = b >> 3, patch = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
         if (patch >= fr.total_patches)
             return;
 #else
         const unsigned int log_waves = 2u + log_gx + log_gy;
-        const unsigned int patch = blockIdx.x >> log_waves, wave = blockIdx.x & ((1u << log_waves) - 1u);
+        const unsigned int patch = block_index >> log_waves, wave = block_index & ((1u << log_waves) - 1u);
 #endif
         // the patch as (16 gx) x (16 gy) lane positions, cut into 8x8 wave tiles: position (vx, vy) is sample
         // (vy % gy) * gx + vx % gx of pixel (vx / gx, vy / gy)
@@ -67,7 +70,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         base_lane = lane - (sy * 8u + sx);
         locate_patch_pixel(fr, patch, (int)(vx >> log_gx), (int)(vy >> log_gy), px, py, out_index, store, inside);
     } else
-        locate_pixel(fr, blockIdx.x, px, py, out_index, store, inside);
+        locate_pixel(fr, block_index, px, py, out_index, store, inside);
 
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
     const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);

@@ -51,7 +51,8 @@ void shray_host_free_world(shray_host_world *world);
 int shray_host_get_world_info(const shray_host_world *world, shray_host_world_info *info);
 
 /* get_shader_data() (world.h:95).  The arrays named by *desc stay owned by
- * `world` and valid until it is freed or flattened again. */
+ * `world` and valid until it is freed.  One flattening is kept per
+ * data_texture_width: asking again for the same width returns the same arrays. */
 int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width, shray_scene_desc *desc);
 
 /* The BVH as plain pre-order arrays (shray_tree_desc, shader_ray_hip.h) for the GPU-side flattener

@@ -14,6 +14,7 @@ HOST_LIB = os.path.join(PKG_DIR, "libshray_host.so")
 HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
+ABI_VERSION = 3   # SHRAY_ABI_VERSION of the header these structures mirror (tests/test_abi.py compares the two)
 
 
 class SceneDesc(C.Structure):
@@ -171,8 +172,9 @@ def load_hip():
         except ImportError:
             pass
         _hip = _bind(C.CDLL(HIP_LIB), HIP_SYMBOLS)
-        if _hip.shray_abi_version() != 1:
-            raise RuntimeError("libshray_hip.so ABI version mismatch")
+        if _hip.shray_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libshray_hip.so reports ABI version {_hip.shray_abi_version()}, these bindings mirror "
+                               f"version {ABI_VERSION} of include/shader_ray_hip.h: rebuild the library")
     return _hip
 
 

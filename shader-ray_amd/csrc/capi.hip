@@ -882,12 +882,8 @@ int shray_render(shray_scene *scene, const shray_frame_params *params, int width
     rc = shray_render_device(scene, params, width, height, spp, nullptr, scene->frame.p, stream);
     if (rc)
         return rc;
-    if (is_pinned_host(rgba_out_host)) {   // one DMA straight into the caller's buffer
-        HIP_TRY(hipMemcpyAsync(rgba_out_host, scene->frame.p, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        return SHRAY_OK;
-    }
-    // pageable destination: the runtime stages it through its own pinned buffers
+    // pinned destination (shray_pinned_alloc): one DMA straight into the caller's buffer; pageable: the runtime
+    // stages the copy through its own pinned buffers -- the same call either way
     HIP_TRY(hipMemcpyAsync(rgba_out_host, scene->frame.p, bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return SHRAY_OK;

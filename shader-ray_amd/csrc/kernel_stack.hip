@@ -171,7 +171,10 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock) * sample_lanes;
     const unsigned int grid_patches = (SHRAY_WAVE_BLOCKS == 2 && !view_instance) ? ((first.total_patches + 7u) & ~7u) : first.total_patches;
     // convergent instances: the frames of the launch interleaved along grid.x (see the kernel); the view instances keep grid.y = frame
-    const bool interleave = SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES && !view_instance && count > 1;
+    // (HIP rejects a launch whose gridDim.x * blockDim.x reaches 2^32: a batch that large -- 4K at 16 spp from 33 frames
+    // on -- goes back to grid.y = frame, which the kernel tells by gridDim.y > 1)
+    const bool interleave = SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES && !view_instance && count > 1 &&
+                            (unsigned long long)grid_patches * per_patch * (unsigned long long)count * kBatchBlock < (1ull << 32);
     const dim3 grid(grid_patches * per_patch * (interleave ? (unsigned)count : 1u), interleave ? 1u : (unsigned)count),
         block(view_instance ? kBlock : kBatchBlock);
     const size_t lds_bytes = view_instance ? stack_lds_bytes(stack_levels) : stack_lds_bytes(stack_levels, kBatchBlock);

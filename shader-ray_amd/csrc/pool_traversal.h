@@ -50,6 +50,10 @@ struct PoolTraversal {
     uint32_t *stack;    // LDS: levels x BLOCK, column-major ([level][column])
     uint32_t *xbuf;     // LDS: kPoolXbufDwords
     uint32_t *counts;   // LDS: kPoolCountDwords
+    // which half of `counts` the next epoch publishes into.  It alternates per epoch ACROSS closest() calls: a
+    // parity restarted at every call would let a fast wave's epoch-0 write of the next call land in the half a
+    // slower wave is still reading for the last epoch of this one (no barrier lies between the two)
+    unsigned int parity = 0;
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -72,7 +76,8 @@ struct PoolTraversal {
         for (int epoch = 0;; epoch++) {
             // ---- the waves meet: live rays per wave (every live ray is in LT_WALK here)
             const unsigned long long live_mask = wave_ballot(busy);
-            uint32_t *cnt = counts + 4 * (epoch & 1);
+            uint32_t *cnt = counts + 4 * parity;
+            parity ^= 1u;
             if (lane == 0)
                 cnt[wave] = (uint32_t)__popcll(live_mask);
             __syncthreads();

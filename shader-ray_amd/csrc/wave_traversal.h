@@ -352,6 +352,13 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
 // overwrites, the test is `>`).  Each worker keeps that rule over its own increasing j, the group combines
 // by (smaller d, then larger j), the parked lane applies the winner.  Same arithmetic on the same values:
 // bit-identical hits; the counting twin tallies the same triangle tests (in the worker lanes).
+//
+// That argument needs the candidates' d to be ORDERED.  A candidate whose d is NaN (a triangle so large that its
+// determinant overflows to inf - inf, or a ray that already carries NaNs) fails none of the shader's comparisons:
+// the sequential loop accepts it, and after it accepts whatever candidate comes next -- an order-dependent
+// outcome no (d, j) ranking reproduces.  A worker that accepts an unordered d raises a flag; if any lane of the
+// wave did, the stage discards the dealt result and runs the plain sequential loop over the untouched parked
+// rays (tests/test_gpu_parity.py::test_nan_candidates_in_a_dealt_leaf).
 #ifndef SHRAY_DEAL_LEAVES
 #define SHRAY_DEAL_LEAVES 1
 #endif
@@ -425,6 +432,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     const uint32_t end = worker ? first + count : 0u;
     float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
     uint32_t best = 0xffffffffu;    // no candidate accepted
+    bool unordered = false;         // accepted a candidate whose d is NaN (see above)
     SHRAY_DIAG_COUNT(6);
     for (uint32_t tri = first + (uint32_t)sub; wave_ballot(tri < end); tri += (uint32_t)G) {
         SHRAY_DIAG_COUNT(1);
@@ -439,8 +447,15 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
                 best_u = u;
                 best_w = w;
                 best = tri;
+                unordered = unordered || d != d;
             }
         }
+    }
+    if (__builtin_expect(wave_ballot(unordered) != 0ull, 0)) {
+        asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
+        // the parked rays have not been touched yet; the triangle tests were tallied above
+        leaf_stage<false, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG_FWD);
+        return;
     }
     // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
     for (int step = 1; step < G; step <<= 1) {

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "background.h"
@@ -16,7 +17,9 @@ bool g_host_quiet = false;
 
 struct shray_host_world {
     world_ptr w;
-    std::vector<std::unique_ptr<scene_shader_data>> flat;   // every flattening handed out stays valid until the world is freed
+    // at most one flattening per data_texture_width: asking again for a width reuses it (the tree does not change
+    // after load_world), so a caller that re-flattens per frame does not grow memory
+    std::vector<std::pair<unsigned int, std::unique_ptr<scene_shader_data>>> flat;
     // shray_host_export_tree
     std::vector<int32_t> tree_parent, tree_negative, tree_positive, tree_start, tree_triangles, tri_vertices;
     std::vector<float> tree_box, tree_direction;
@@ -71,12 +74,19 @@ int shray_host_flatten(shray_host_world *world, unsigned int data_texture_width,
 {
     if (!world || !desc || data_texture_width == 0)
         return -1;
-    std::unique_ptr<scene_shader_data> fresh(new scene_shader_data);
-    get_shader_data(world->w, *fresh, data_texture_width);
-    if (!fresh->links_complete)
-        return -1;   // upstream asserts here (world.cpp:228): never hand out half-threaded link tables
-    world->flat.push_back(std::move(fresh));
-    scene_shader_data &d = *world->flat.back();
+    scene_shader_data *found = nullptr;
+    for (auto &entry : world->flat)
+        if (entry.first == data_texture_width)
+            found = entry.second.get();
+    if (!found) {
+        std::unique_ptr<scene_shader_data> fresh(new scene_shader_data);
+        get_shader_data(world->w, *fresh, data_texture_width);
+        if (!fresh->links_complete)
+            return -1;   // upstream asserts here (world.cpp:228): never hand out half-threaded link tables
+        world->flat.emplace_back(data_texture_width, std::move(fresh));
+        found = world->flat.back().second.get();
+    }
+    scene_shader_data &d = *found;
 
     memset(desc, 0, sizeof(*desc));
     desc->struct_size = (uint32_t)sizeof(*desc);

@@ -140,6 +140,35 @@ def test_hand_built_edge_cases(pkg, gpu, oracle_mod):
         scene.close()
 
 
+def test_nan_candidates_in_a_dealt_leaf(pkg, gpu, oracle_mod):
+    """A triangle whose determinant overflows gives d = u = v = NaN, which fail none of the shader's comparisons
+    (raytracer.es.fs:312-340): the sequential loop accepts it and then accepts the next candidate whatever its
+    distance.  The dealt leaf stage ranks candidates by (d, index), which cannot express that; it has to notice the
+    unordered candidate and fall back to the sequential loop.  The leaf's box covers a few pixels of each 8x8 wave
+    tile, so the parked rays are few and the stage really deals (G = 4..16 workers per ray); the huge triangle sits
+    before, between and after finite hits, in the same worker's share and in another's."""
+    import test_oracle_kat as kat
+    env = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    for material in (0, 6):
+        for bounces in (1, 3):
+            params = default_params(pkg, 16, 16, zoom=3.0, material=material)
+            params.bounce_count = bounces
+            for order in kat.NAN_ORDERS:
+                hand = kat.nan_leaf_scene(order)
+                scene = pkg.Scene(hand.desc, env, device=0)
+                want, cpu = oracle_mod.render(hand.desc, env, params, 16, 16, 1)
+                assert not np.isnan(want).any()       # the tone map turns a NaN radiance into 0 (max(0, NaN) = 0)
+                for kernel in KERNELS:
+                    scene.set_kernel(kernel)
+                    got, counters = scene.render_counters(params, 16, 16, 1)     # 256-thread twin: dealt leaf stage
+                    plain = scene.render(params, 16, 16, 1)                      # one-wave instance: dealt (one frame per launch)
+                    what = f"order {order}, material {material}, {bounces} bounce(s), kernel {kernel}"
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), what
+                    assert np.array_equal(plain.view(np.uint32), want.view(np.uint32)), what + " (timed instance)"
+                    assert counters == cpu, (what, counters, cpu)
+                scene.close()
+
+
 def test_empty_world_renders_environment(pkg, gpu, oracle_mod, tmp_path):
     path = tmp_path / "empty.trisrc"
     path.write_text("")

@@ -507,3 +507,48 @@ def test_view_1_filters_the_environment_with_the_ray_differentials(pkg, oracle_m
     p2.which = 0
     b, _ = oracle_mod.render(far_away_triangle().desc, env, p2, 960, 540, rows=(100, 102))
     assert np.allclose(a[100:102], b[100:102], rtol=2e-3, atol=1e-4)
+
+
+# ---- NaN candidates in a leaf (raytracer.es.fs:312-346): a triangle so large that its determinant overflows
+# fails none of the shader's comparisons, so the sequential loop accepts it (hit.t = NaN) and then accepts
+# whatever candidate comes next, whatever its distance
+HUGE_TRIANGLE = [[-1e30, -1e30, 0.0], [1e30, -1e30, 0.0], [0.0, 1e30, 0.0]]   # det = inf, d = u = v = NaN for every ray
+
+
+def finite_triangle(z):
+    return [[-2.0, -2.0, z], [2.0, -2.0, z], [0.0, 2.0, z]]
+
+
+def nan_leaf_scene(order, half=0.25):
+    """One leaf whose box is the cube [-half, half]^3 (hand-set: it does not enclose the huge triangle) holding,
+    in the order given, 'nan' = the huge triangle, or a z value = a finite triangle in the plane of that z."""
+    tris = [HUGE_TRIANGLE if k == "nan" else finite_triangle(float(k)) for k in order]
+    tp = np.asarray(tris, dtype=np.float32)
+    normals = np.tile(np.asarray([0.0, 0.0, 1.0], np.float32), (len(tris) * 3, 1))
+    hm = np.full((8, 1, 2), END, dtype=np.float32)
+    return HandScene(tp.reshape(-1, 3), normals, [[-half] * 3], [[half] * 3], hm, [[0, len(tris)]], 0)
+
+
+NAN_ORDERS = [("nan", 0.1), (0.1, "nan"), ("nan", 0.1, -0.1), (0.1, "nan", -0.1), (0.1, -0.1, "nan"), (-0.1, "nan", 0.1),
+              ("nan", -0.1, 0.1), (-0.1, 0.1, "nan"), (0.2, 0.1, 0.0, "nan", -0.1, -0.2, 0.15), (0.0, "nan", "nan", 0.1, 0.2),
+              (0.05, 0.1, 0.15, "nan"), ("nan",)]
+
+
+def test_nan_candidate_is_accepted_and_resets_the_comparison(pkg, oracle_mod):
+    """After a NaN candidate every comparison with hit.t is false: the next candidate in order is accepted whatever
+    its distance, and the loop goes on from there.  So the leaf's outcome is that of the triangles AFTER the last
+    huge one, or a NaN hit (tone-mapped to 0) if none follows."""
+    env = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    p = default_params(pkg, 16, 16, zoom=3.0)
+    p.bounce_count = 1    # one traversal per pixel: a reflected ray would meet the huge triangle again
+    for order in NAN_ORDERS:
+        got, _ = oracle_mod.render(nan_leaf_scene(order).desc, env, p, 16, 16, 1)
+        last = max(k for k, what in enumerate(order) if what == "nan")
+        tail = order[last + 1:]
+        centre = got[8, 8]
+        if not tail:
+            assert centre.tolist() == [0.0, 0.0, 0.0, 1.0], (order, centre)
+        else:
+            want, _ = oracle_mod.render(nan_leaf_scene(tail).desc, env, p, 16, 16, 1)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), order
+            assert not np.isnan(got).any()

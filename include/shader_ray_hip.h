@@ -215,6 +215,8 @@ int shray_device_flat_destroy(shray_device_flat *flat);
 int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene);
 int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height);
 int shray_scene_destroy(shray_scene *scene);
+/* The HIP device the scene's buffers live on (the device that was current when it was created). */
+int shray_scene_device(const shray_scene *scene, int *device_index);
 
 /* Kernel selection: 0 = per-ray LDS stack kernel (default), 1 = literal threaded hit/miss-table traversal
  * over the reference arrays, 2 = pool kernel (a workgroup's waves merge their live rays while they

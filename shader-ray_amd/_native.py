@@ -10,6 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB = os.path.join(PKG_DIR, "libshray_host.so")
+DIST_LIB = os.path.join(PKG_DIR, "libshray_dist.so")
 # SHRAY_HIP_LIB selects an experiment build of the same library (profiles/variant_sweep.sh); unset in normal use
 HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip.so")
 
@@ -101,6 +102,7 @@ HIP_SYMBOLS = [
     ("shray_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("shray_scene_set_environment", C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int]),
     ("shray_scene_destroy", C.c_int, [C.c_void_p]),
+    ("shray_scene_device", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("shray_scene_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
     ("shray_render", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, c_float_p]),
     ("shray_render_host_async", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -138,8 +140,65 @@ HOST_SYMBOLS = [
     ("shray_host_set_quiet", None, [C.c_int]),
 ]
 
+# include/shader_ray_dist.h ------------------------------------------------------------------------------
+DIST_ROOT0, DIST_ROTATE = 0, 1
+DIST_RCCL, DIST_LOOPBACK, DIST_CALLBACK = 0, 1, 2
+DIST_UNIQUE_ID_BYTES = 128
+MAX_BATCH = 64
+DIST_MAX_WORLD = 64
+
+
+class DistConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("rank", C.c_int32), ("world", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("max_frames", C.c_int32), ("root_mode", C.c_int32),
+                ("rank0_phases", C.c_int32), ("other_phases", C.c_int32), ("rgb_wire", C.c_int32),
+                ("transport", C.c_int32), ("buffer_sets", C.c_int32)]
+
+
+class DistXfer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("frame", C.c_int32), ("offset_bytes", C.c_int64), ("bytes", C.c_int64)]
+
+
+class DistPlan(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("tiles", TileSet), ("rank0_phases", C.c_int32), ("other_phases", C.c_int32),
+                ("channels", C.c_int32), ("max_assembled", C.c_int32), ("owned_tiles", C.c_int64), ("max_tiles", C.c_int64),
+                ("render_frame_stride_bytes", C.c_int64), ("wire_frame_stride_bytes", C.c_int64),
+                ("gather_rank_stride_bytes", C.c_int64), ("gather_frame_stride_bytes", C.c_int64)]
+
+
+DIST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DistXfer), C.c_int, C.c_void_p, C.POINTER(DistXfer),
+                               C.c_int, C.c_void_p)
+
+
+class DistCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", DIST_EXCHANGE_FN)]
+
+
+DIST_SYMBOLS = [
+    ("shray_dist_last_error", C.c_char_p, []),
+    ("shray_dist_balanced_shares", C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("shray_dist_make_plan", C.c_int, [C.POINTER(DistConfig), C.POINTER(DistPlan)]),
+    ("shray_dist_frame_owner", C.c_int, [C.POINTER(DistConfig), C.c_int]),
+    ("shray_dist_step_xfers", C.c_int, [C.POINTER(DistConfig), C.c_int, C.POINTER(DistXfer), C.POINTER(C.c_int),
+                                        C.POINTER(DistXfer), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]),
+    ("shray_dist_unique_id", C.c_int, [C.c_void_p]),
+    ("shray_dist_hub_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("shray_dist_hub_destroy", C.c_int, [C.c_void_p]),
+    ("shray_dist_create", C.c_int, [C.c_void_p, C.POINTER(DistConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("shray_dist_destroy", C.c_int, [C.c_void_p]),
+    ("shray_dist_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(FrameParams), C.c_int, C.c_void_p]),
+    ("shray_dist_output", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_void_p)]),
+    ("shray_dist_copy_output", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("shray_dist_copy_to_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("shray_dist_copy_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+]
+
 _host = None
 _hip = None
+_dist = None
 
 
 def _bind(lib, table):
@@ -176,6 +235,23 @@ def load_hip():
             raise RuntimeError(f"libshray_hip.so reports ABI version {_hip.shray_abi_version()}, these bindings mirror "
                                f"version {ABI_VERSION} of include/shader_ray_hip.h: rebuild the library")
     return _hip
+
+
+def load_dist():
+    """Loads the multi-GPU frame loop (libshray_dist.so: depends on libshray_hip.so and RCCL)."""
+    global _dist
+    if _dist is None:
+        load_hip()    # torch first, then the HIP layer: one HIP runtime, one RCCL (torch bundles both)
+        if not os.path.exists(DIST_LIB):
+            raise RuntimeError(f"{DIST_LIB} is not built; run `python __graft_entry__.py build` (or `make -C shader-ray_amd`)")
+        _dist = _bind(C.CDLL(DIST_LIB), DIST_SYMBOLS)
+    return _dist
+
+
+def check_dist(code: int):
+    if code != 0:
+        msg = load_dist().shray_dist_last_error()
+        raise ShrayError(code, msg.decode() if msg else "")
 
 
 class ShrayError(RuntimeError):

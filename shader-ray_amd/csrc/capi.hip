@@ -711,6 +711,14 @@ int shray_scene_destroy(shray_scene *scene)
     return SHRAY_OK;
 }
 
+int shray_scene_device(const shray_scene *scene, int *device_index)
+{
+    if (!scene || !device_index)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or device_index is NULL");
+    *device_index = scene->device;
+    return SHRAY_OK;
+}
+
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
     if (!scene || kernel_id < 0 || kernel_id > 2)

@@ -1,22 +1,20 @@
-"""Frame tiling across the GPUs of one node.
+"""Frame tiling across the GPUs of one node: a thin Python face of libshray_dist.so
+(include/shader_ray_dist.h), where one rank's whole step lives in C++:
 
-Pixels are independent (reference raytracer.es.fs:613-682 reads no neighbour), so a frame
-shards by pixel: the scene and environment are replicated on every GPU, the frame is cut
-into tile_w x tile_h tiles numbered row-major, rank r renders the tiles with
-index % world_size == r (interleaved, because the object sits mid-frame and contiguous
-bands would be unbalanced) and packs them densely; one gather of the packed tile buffers to
-rank 0 (RCCL over xGMI: every peer sends on its own link) is the only exchange step; rank 0
-de-interleaves.  Samples of a pixel never leave their GPU, so there is no reduction.
+    this rank's tiles of `count` frames (one launch) -> pack (RGB on the wire) -> grouped
+    ncclSend / ncclRecv over xGMI -> de-interleave on the rank that assembles the frame
 
-Shares: rank 0 also packs nothing less than its peers but additionally receives every buffer and
-de-interleaves the frames, so it owns fewer tiles: the tiles are dealt in periods of
-c0 + (world - 1) * c1 phases, of which rank 0 takes the first c0 and every other rank c1 (c0 <= c1;
-`balanced_shares`).  shray_tile_set / shray_assemble_tiles_split_device speak the same scheme.
+Pixels are independent (reference raytracer.es.fs:613-682 reads no neighbour), so a frame shards by
+pixel: scene and environment are replicated on every GPU, tiles are dealt round robin (the object
+sits mid-frame, contiguous bands would be unbalanced) and all samples of a pixel stay on its GPU --
+no reduction, one exchange step.  Two root modes: ROOT0 gathers every frame on rank 0 (which may own
+a smaller share of the tiles); ROTATE assembles frame f of a step on rank f % world, so that all
+world * (world - 1) directed links carry pixels instead of the 7 into rank 0.
 
-Frames per step: a rank's share of ONE 1080p frame is latency-bound -- the frame's few
-long-running waves take ~0.5 ms wherever they land, whatever the share (profiles/r01) -- so a
-step carries `frames` consecutive frames: one launch (shray_render_batch_device), one larger
-gather, one de-interleave.
+What is left here: the ctypes marshalling (`Rank`), the plan queries (`plan`, `step_xfers`: host-only,
+usable without a GPU), a numpy statement of the tile mapping for tests (`owned_tiles`, `tile_owner`,
+`assemble_tiles`), and `HostExchange`: the CALLBACK transport over torch.distributed / gloo, which is
+how `bench.py`'s multi-rank control flow is rehearsed on a one-GPU box.  Nothing here renders.
 """
 from __future__ import annotations
 
@@ -27,28 +25,61 @@ import numpy as np
 from . import _native as N
 
 DEFAULT_TILE = 32
+ROOT0, ROTATE = N.DIST_ROOT0, N.DIST_ROTATE
+RCCL, LOOPBACK, CALLBACK = N.DIST_RCCL, N.DIST_LOOPBACK, N.DIST_CALLBACK
 
 
-# rank 0's extra work per frame (receive + de-interleave + its larger pack) as a fraction of ONE GPU's time for a
-# whole frame: 0.017 ms of 0.28 ms on MI355X; only the shares depend on it, never the image
-RANK0_OVERHEAD = 0.06
+# ---- the plan (host only) ----------------------------------------------------------------------------
+def balanced_shares(world: int, overhead: float = -1.0):
+    """(c0, c1): tile phases per period for rank 0 and for every other rank (shray_dist_balanced_shares)."""
+    c0, c1 = C.c_int(), C.c_int()
+    N.check_dist(N.load_dist().shray_dist_balanced_shares(world, overhead, C.byref(c0), C.byref(c1)))
+    return c0.value, c1.value
 
 
-def balanced_shares(world: int, overhead: float = RANK0_OVERHEAD, largest: int = 8):
-    """(c0, c1): phases per period for rank 0 and for every other rank that minimise the slowest rank's
-    time, c0 / period + overhead against c1 / period, period = c0 + (world - 1) * c1."""
-    if world <= 1:
-        return 1, 1
-    best = None
-    for c1 in range(1, largest + 1):
-        for c0 in range(1, c1 + 1):
-            period = c0 + (world - 1) * c1
-            cost = max(c0 / period + overhead, c1 / period)
-            if best is None or cost < best[0] - 1e-12:
-                best = (cost, c0, c1)
-    return best[1], best[2]
+def make_config(rank: int, world: int, width: int, height: int, spp: int = 1, frames: int = 1, root_mode: int = ROOT0,
+                transport: int = RCCL, shares=None, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE,
+                rgb_wire: bool = True, buffer_sets: int = 2) -> N.DistConfig:
+    cfg = N.DistConfig()
+    cfg.struct_size = C.sizeof(N.DistConfig)
+    cfg.rank, cfg.world = rank, world
+    cfg.width, cfg.height, cfg.spp = width, height, spp
+    cfg.tile_w, cfg.tile_h = tile_w, tile_h
+    cfg.max_frames = frames
+    cfg.root_mode = root_mode
+    cfg.rank0_phases, cfg.other_phases = shares if shares is not None else (0, 0)
+    cfg.rgb_wire = 1 if rgb_wire else 0
+    cfg.transport = transport
+    cfg.buffer_sets = buffer_sets
+    return cfg
 
 
+def plan(cfg: N.DistConfig) -> N.DistPlan:
+    p = N.DistPlan()
+    N.check_dist(N.load_dist().shray_dist_make_plan(C.byref(cfg), C.byref(p)))
+    return p
+
+
+def frame_owner(cfg: N.DistConfig, frame: int) -> int:
+    rank = N.load_dist().shray_dist_frame_owner(C.byref(cfg), frame)
+    if rank < 0:
+        N.check_dist(rank)
+    return rank
+
+
+def step_xfers(cfg: N.DistConfig, count: int):
+    """(sends, recvs, assembled, first_frame, frame_step) of a step of `count` frames for cfg.rank; sends / recvs
+    are lists of (peer, frame, offset_bytes, bytes)."""
+    cap = N.MAX_BATCH + N.DIST_MAX_WORLD
+    sends, recvs = (N.DistXfer * cap)(), (N.DistXfer * cap)()
+    ns, nr, asm, first, step = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    N.check_dist(N.load_dist().shray_dist_step_xfers(C.byref(cfg), count, sends, C.byref(ns), recvs, C.byref(nr), C.byref(asm),
+                                                     C.byref(first), C.byref(step)))
+    as_list = lambda arr, n: [(x.peer, x.frame, x.offset_bytes, x.bytes) for x in arr[:n]]   # noqa: E731
+    return as_list(sends, ns.value), as_list(recvs, nr.value), asm.value, first.value, step.value
+
+
+# ---- the tile mapping in numpy: an independent statement for tests -------------------------------------
 def rank_phases(world: int, rank: int, shares=(1, 1)):
     """(period, first phase, phase count) of `rank` under shares (c0, c1)."""
     c0, c1 = shares
@@ -75,38 +106,7 @@ def tile_owner(t: int, world: int, shares=(1, 1)):
     return 1 + (phase - c0) // c1, rnd * c1 + (phase - c0) % c1
 
 
-def assemble_tiles(parts, width: int, height: int, tile_w: int, tile_h: int, shares=(1, 1)) -> np.ndarray:
-    """De-interleaves the packed tile buffers of all ranks (list index = rank) into one
-    [height, width, 4] frame.  Works on numpy arrays; see assemble_tiles_torch for the
-    device-side form of the even split."""
-    world = len(parts)
-    frame = np.zeros((height, width, 4), dtype=np.float32)
-    tiles_x = (width + tile_w - 1) // tile_w
-    tiles_y = (height + tile_h - 1) // tile_h
-    packed = [np.asarray(flat, dtype=np.float32).reshape(-1, tile_h, tile_w, 4) for flat in parts]
-    for t in range(tiles_x * tiles_y):
-        rank, k = tile_owner(t, world, shares)
-        x0, y0 = (t % tiles_x) * tile_w, (t // tiles_x) * tile_h
-        w, h = min(tile_w, width - x0), min(tile_h, height - y0)
-        frame[y0:y0 + h, x0:x0 + w] = packed[rank][k, :h, :w]
-    return frame
-
-
-def assemble_tiles_torch(gathered, width: int, height: int, tile_w: int, tile_h: int):
-    """`gathered` is a [world, max_tiles, tile_h, tile_w, 4] tensor (rank-major, as gathered, EVEN split);
-    returns the [height, width, 4] frame on the same device using one permute + crop."""
-    import torch
-    world, max_tiles = gathered.shape[0], gathered.shape[1]
-    tiles_x = (width + tile_w - 1) // tile_w
-    tiles_y = (height + tile_h - 1) // tile_h
-    # tile t lives at gathered[t % world, t // world]
-    by_tile = gathered.permute(1, 0, 2, 3, 4).reshape(max_tiles * world, tile_h, tile_w, 4)[: tiles_x * tiles_y]
-    grid = by_tile.reshape(tiles_y, tiles_x, tile_h, tile_w, 4).permute(0, 2, 1, 3, 4)
-    return grid.reshape(tiles_y * tile_h, tiles_x * tile_w, 4)[:height, :width].contiguous()
-
-
 def max_tiles_per_rank(width: int, height: int, tile_w: int, tile_h: int, world: int, shares=(1, 1)) -> int:
-    """The largest packed buffer among the ranks, in tiles (a gather moves equal-sized buffers)."""
     tiles_x = (width + tile_w - 1) // tile_w
     tiles_y = (height + tile_h - 1) // tile_h
     total = tiles_x * tiles_y
@@ -117,111 +117,155 @@ def max_tiles_per_rank(width: int, height: int, tile_w: int, tile_h: int, world:
     return most
 
 
-class DistributedFrame:
-    """`frames` consecutive frames split across the ranks of a torch.distributed group, reusable.
+def assemble_tiles(parts, width: int, height: int, tile_w: int, tile_h: int, shares=(1, 1), channels: int = 4) -> np.ndarray:
+    """De-interleaves the packed tile buffers of all ranks (list index = rank, `channels` floats per pixel) into one
+    [height, width, 4] frame (alpha = 1 when only R, G, B travelled)."""
+    world = len(parts)
+    frame = np.ones((height, width, 4), dtype=np.float32)
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    per_tile = tile_h * tile_w * channels
+    for t in range(tiles_x * tiles_y):
+        rank, k = tile_owner(t, world, shares)
+        tile = np.asarray(parts[rank], dtype=np.float32).reshape(-1)[k * per_tile:(k + 1) * per_tile].reshape(tile_h, tile_w, channels)
+        x0, y0 = (t % tiles_x) * tile_w, (t // tiles_x) * tile_h
+        w, h = min(tile_w, width - x0), min(tile_h, height - y0)
+        frame[y0:y0 + h, x0:x0 + w, :channels] = tile[:h, :w]
+    return frame
 
-    All buffers are allocated once: this rank's packed tile buffer ([frames, tiles, tile_h,
-    tile_w, 4], what the kernel writes), its wire buffer and, on rank 0, one [world, frames, ...]
-    receive buffer whose rows are the gather targets and the assembled [frames, height, width, 4]
-    output.  A step is: render (one launch for all `frames`) -> pack -> ONE gather -> one
-    permute/crop copy.  Nothing synchronises with the host.
 
-    Wire format: alpha is the constant 1 for every pixel of a frame (raytracer.es.fs:676), so
-    with `rgb_wire` only R, G, B travel (12 instead of 16 bytes per pixel over xGMI) and rank 0
-    writes them into an output whose alpha plane is already 1."""
+# ---- one rank of the frame loop ------------------------------------------------------------------------
+class Hub:
+    """The LOOPBACK transport's in-process meeting point: ranks are threads of this process sharing one GPU."""
 
-    def __init__(self, width: int, height: int, tile_w: int = DEFAULT_TILE, tile_h: int = DEFAULT_TILE, group=None,
-                 device=None, always_gather: bool = False, stage_through_host: bool = False, frames: int = 1,
-                 rgb_wire: bool = True, shares=None):
-        import torch
-        import torch.distributed as dist
-        self.width, self.height, self.tile_w, self.tile_h = width, height, tile_w, tile_h
-        self.group = group
-        self.frames = frames
-        self.channels = 3 if rgb_wire else 4
-        self.always_gather = always_gather   # run the collective even with one rank (rehearsal)
-        self.stage_through_host = stage_through_host   # gloo rehearsal: the collective moves host copies
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # rank 0 owns fewer tiles than its peers (it also receives and de-interleaves): (c0, c1) phases per period
-        self.shares = tuple(shares) if shares is not None else balanced_shares(self.world)
-        self.per_rank = max_tiles_per_rank(width, height, tile_w, tile_h, self.world, self.shares)
-        self.pixels = self.per_rank * tile_h * tile_w          # per frame, padded to whole tiles
-        self.mine = torch.zeros(frames, self.pixels * 4, dtype=torch.float32, device=device)
-        self.wire = torch.zeros(frames, self.pixels * 3, dtype=torch.float32, device=device) if rgb_wire else self.mine
-        period, phase, count = rank_phases(self.world, self.rank, self.shares)
-        self.tiles = N.TileSet(tile_w, tile_h, period, phase, count)
-        self.received = None
-        self.output = None
-        if self.rank == 0:
-            self.received = torch.zeros(self.world, frames, self.pixels * self.channels, dtype=torch.float32, device=device)
-            self.output = torch.ones(frames, height, width, 4, dtype=torch.float32, device=device)
+    def __init__(self, world: int):
+        self._lib = N.load_dist()
+        h = C.c_void_p()
+        N.check_dist(self._lib.shray_dist_hub_create(world, C.byref(h)))
+        self.handle = h
 
-    @property
-    def frame_stride_bytes(self) -> int:
-        return self.pixels * 16
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.shray_dist_hub_destroy(self.handle)
+            self.handle = None
 
-    def render(self, render_tiles, count: int | None = None):
-        """`render_tiles(tile_set, out_tensor)` fills this rank's packed tiles of `count` (default:
-        all `frames`) frames, frame k at out_tensor[k] (on a GPU box that is
-        Scene.render_batch_into; the CPU rehearsal passes an oracle-backed stand-in).  Returns the
-        assembled frames on rank 0 -- [height, width, 4] when the object holds one frame, else
-        [count, height, width, 4] -- and None elsewhere."""
-        import torch.distributed as dist
-        count = self.frames if count is None else count
-        assert 1 <= count <= self.frames
-        mine = self.mine[:count]
-        render_tiles(self.tiles, mine)
-        wire = mine
-        if self.channels == 3:
-            wire = self.wire[:count]
-            wire.view(count, self.pixels, 3).copy_(mine.view(count, self.pixels, 4)[:, :, :3])
-        if self.world == 1 and not self.always_gather:
-            return self._assemble(wire.unsqueeze(0), count)
-        sink = [self.received[r, :count] for r in range(self.world)] if self.rank == 0 else None
-        if self.stage_through_host:
-            wire_host = wire.cpu()
-            sink_host = [t.cpu() for t in sink] if self.rank == 0 else None
-            dist.gather(wire_host, sink_host, dst=0, group=self.group)
-            if self.rank == 0:
-                for dst, src in zip(sink, sink_host):
-                    dst.copy_(src)
+
+def unique_id() -> bytes:
+    """An RCCL unique id (rank 0 makes one and hands it to the others over any side channel)."""
+    buf = C.create_string_buffer(N.DIST_UNIQUE_ID_BYTES)
+    N.check_dist(N.load_dist().shray_dist_unique_id(buf))
+    return buf.raw
+
+
+class Rank:
+    """shray_dist: this rank's step of the multi-GPU frame loop.  `scene` is the rank's replica
+    (tracer.Scene); `transport_arg`: RCCL -> the unique id bytes, LOOPBACK -> a Hub, CALLBACK -> an object with
+    an `exchange_device(d_wire, sends, d_gather, recvs, stream_ptr)` method (HostExchange)."""
+
+    def __init__(self, scene, cfg: N.DistConfig, transport_arg):
+        self._lib = N.load_dist()
+        self.cfg = cfg
+        self.scene = scene                    # keeps the replica alive
+        self.plan = plan(cfg)
+        self._keep = transport_arg
+        if cfg.transport == RCCL:
+            arg = C.create_string_buffer(bytes(transport_arg), N.DIST_UNIQUE_ID_BYTES)
+            arg_p = C.cast(arg, C.c_void_p)
+        elif cfg.transport == LOOPBACK:
+            arg_p = transport_arg.handle
         else:
-            dist.gather(wire, sink, dst=0, group=self.group)
-        if self.rank != 0:
-            return None
-        return self._assemble(self.received[:, :count], count)
+            def trampoline(_user, d_wire, sends, ns, d_gather, recvs, nr, stream):
+                try:
+                    transport_arg.exchange_device(d_wire, [(x.peer, x.frame, x.offset_bytes, x.bytes) for x in sends[:ns]],
+                                                  d_gather, [(x.peer, x.frame, x.offset_bytes, x.bytes) for x in recvs[:nr]],
+                                                  stream)
+                    return 0
+                except Exception as exc:   # noqa: BLE001  (an exception must not unwind through the C frames)
+                    print(f"shray exchange callback: {exc!r}", flush=True)
+                    return 1
+            self._fn = N.DIST_EXCHANGE_FN(trampoline)
+            self._cb = N.DistCallbacks(None, self._fn)
+            arg_p = C.cast(C.pointer(self._cb), C.c_void_p)
+        handle = C.c_void_p()
+        N.check_dist(self._lib.shray_dist_create(scene._handle, C.byref(cfg), arg_p, C.byref(handle)))
+        self._handle = handle
 
-    def _assemble(self, gathered, count: int):
-        """gathered: [world, count, pixels * channels], rank-major as gathered."""
+    def step(self, params_list, buffer_set: int = 0, stream_ptr: int = 0):
+        count = len(params_list)
+        array = (N.FrameParams * count)(*params_list)
+        N.check_dist(self._lib.shray_dist_step(self._handle, buffer_set, array, count, C.c_void_p(stream_ptr)))
+
+    def output(self, buffer_set: int, count: int):
+        """(assembled, first_frame, frame_step, device pointer) after a step of `count` frames."""
+        asm, first, step, ptr = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+        N.check_dist(self._lib.shray_dist_output(self._handle, buffer_set, count, C.byref(asm), C.byref(first), C.byref(step),
+                                                 C.byref(ptr)))
+        return asm.value, first.value, step.value, ptr.value
+
+    def frames(self, buffer_set: int, count: int, stream_ptr: int = 0):
+        """{frame index in the step: [height, width, 4] torch tensor on the device} of the frames this rank
+        assembled (copies, enqueued on the stream)."""
         import torch
-        c = self.channels
-        if self.output is None:   # world == 1 without a process group
-            self.output = torch.ones(self.frames, self.height, self.width, 4, dtype=torch.float32, device=gathered.device)
-        if gathered.is_cuda:
-            # the library's de-interleave kernel (shray_assemble_tiles_device), on the current stream
-            assert gathered.stride(2) == 1 and gathered.stride(1) == self.pixels * c
-            N.check(N.load_hip().shray_assemble_tiles_split_device(
-                C.c_void_p(gathered.data_ptr()), self.world, self.shares[0], self.shares[1], count, c,
-                gathered.stride(0) * 4, gathered.stride(1) * 4,
-                self.width, self.height, self.tile_w, self.tile_h, C.c_void_p(self.output.data_ptr()),
-                C.c_void_p(torch.cuda.current_stream(gathered.device).cuda_stream)))
-            return self.output[0] if self.frames == 1 else self.output[:count]
-        # host tensors (the gloo rehearsal): the same mapping through an index table (tile -> rank, slot)
-        tiles_x = (self.width + self.tile_w - 1) // self.tile_w
-        tiles_y = (self.height + self.tile_h - 1) // self.tile_h
-        owners = [tile_owner(t, self.world, self.shares) for t in range(tiles_x * tiles_y)]
-        rank_of = torch.tensor([o[0] for o in owners], dtype=torch.long)
-        slot_of = torch.tensor([o[1] for o in owners], dtype=torch.long)
-        per_tile = gathered.reshape(self.world, count, self.per_rank, self.tile_h, self.tile_w, c)
-        by_tile = per_tile[rank_of, :, slot_of].permute(1, 0, 2, 3, 4)          # [count, tiles, tile_h, tile_w, c]
-        grid = by_tile.reshape(count, tiles_y, tiles_x, self.tile_h, self.tile_w, c).permute(0, 1, 3, 2, 4, 5)
-        image = grid.reshape(count, tiles_y * self.tile_h, tiles_x * self.tile_w, c)[:, : self.height, : self.width]
-        self.output[:count, :, :, :c].copy_(image)
-        return self.output[0] if self.frames == 1 else self.output[:count]
+        asm, first, step, _ = self.output(buffer_set, count)
+        if asm == 0:
+            return {}
+        dev = torch.device("cuda", self.device_index())
+        out = torch.empty(asm, self.cfg.height, self.cfg.width, 4, dtype=torch.float32, device=dev)
+        N.check_dist(self._lib.shray_dist_copy_output(self._handle, buffer_set, count, C.c_void_p(out.data_ptr()), C.c_void_p(stream_ptr)))
+        return {first + k * step: out[k] for k in range(asm)}
+
+    def device_index(self) -> int:
+        d = C.c_int()
+        N.check(N.load_hip().shray_scene_device(self.scene._handle, C.byref(d)))
+        return d.value
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.shray_dist_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def render_frame_distributed(render_tiles, width: int, height: int, tile_w: int = DEFAULT_TILE,
-                             tile_h: int = DEFAULT_TILE, group=None, device=None, shares=None):
-    """One-shot convenience wrapper around DistributedFrame."""
-    return DistributedFrame(width, height, tile_w, tile_h, group, device, rgb_wire=False, shares=shares).render(render_tiles)
+# ---- the CALLBACK transport over torch.distributed (gloo): rehearsal only ------------------------------
+class HostExchange:
+    """Moves a step's transfers between ranks through host memory with torch.distributed point-to-point calls
+    (gloo).  `exchange_host` works on host byte arrays (what the CPU tests drive); `exchange_device` wraps it for
+    the C library's CALLBACK transport: device -> host, exchange, host -> device."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def exchange_host(self, wire: np.ndarray, sends, gather: np.ndarray, recvs):
+        """wire / gather: uint8 views of this rank's wire and gather buffers."""
+        import torch
+        import torch.distributed as dist
+        ops, landing = [], []
+        for peer, _frame, offset, nbytes in recvs:
+            t = torch.empty(nbytes, dtype=torch.uint8)
+            landing.append((t, offset, nbytes))
+            ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+        for peer, _frame, offset, nbytes in sends:
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(wire[offset:offset + nbytes])), peer, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for t, offset, nbytes in landing:
+            gather[offset:offset + nbytes] = t.numpy()
+
+    def exchange_device(self, d_wire, sends, d_gather, recvs, stream_ptr):
+        lib = N.load_dist()
+        wire_end = max((o + b for _, _, o, b in sends), default=0)
+        wire = np.empty(wire_end, dtype=np.uint8)
+        if wire_end:
+            N.check_dist(lib.shray_dist_copy_to_host(wire.ctypes.data_as(C.c_void_p), C.c_void_p(d_wire), wire_end, C.c_void_p(stream_ptr)))
+        hi = max((o + b for _, _, o, b in recvs), default=0)
+        gather = np.empty(hi, dtype=np.uint8)
+        self.exchange_host(wire, sends, gather, recvs)
+        for _peer, _frame, offset, nbytes in recvs:
+            N.check_dist(lib.shray_dist_copy_to_device(C.c_void_p(d_gather + offset), gather[offset:].ctypes.data_as(C.c_void_p), nbytes,
+                                                       C.c_void_p(stream_ptr)))

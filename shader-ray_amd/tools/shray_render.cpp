@@ -8,21 +8,131 @@
 //                              `frames` frames, print the reference's benchmark histogram (the 'B' key,
 //                              ray.cpp:1096-1131: 10 buckets of frame time / fps) and save the last frame
 //                [-f prefix]   also dump every frame as raw RGBA float32 to <prefix>NNN.rgba (row 0 = bottom)
+//                [-g N]        N GPUs: one thread per GPU, each with a replica of the scene; the frames of the
+//                              animation are rendered in steps of N (every rank its interleaved tiles of all N, one
+//                              launch), exchanged over xGMI (RCCL) and assembled -- shader_ray_dist.h.
+//                [-r mode]     with -g: root0 (every frame assembled on GPU 0) or rotate (frame f on GPU f % N; default)
+//                [-t name]     with -g: rccl (default) or loopback (all ranks share GPU 0: rehearsal on a one-GPU box)
 //
 // background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
 // (host/background.cpp; the reference decodes image files through FreeImagePlus).
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "background.h"
 #include "frame-params.h"
+#include "shader_ray_dist.h"
 #include "shader_ray_hip.h"
 #include "world.h"
+
+namespace {
+
+// -g N: the frame loop of ray.cpp:1096-1131 on N GPUs.  Every rank (thread) renders its tiles of `world` consecutive
+// frames per step; with rotating roots frame f of a step ends up, whole, on rank f % world, which copies it to its
+// slot of `frames_out` (pinned host memory, the animation's frames back to back) when `keep_frames` is set.
+struct multi_gpu_job {
+    int world = 1, width = 0, height = 0, spp = 1, frames = 1;
+    int root_mode = SHRAY_DIST_ROTATE, transport = SHRAY_DIST_RCCL;
+    const shray_scene_desc *desc = nullptr;
+    const float *env = nullptr;
+    int env_w = 0, env_h = 0;
+    const std::vector<shray_frame_params> *params = nullptr;
+    float *frames_out = nullptr;      // frames * width * height * 4 floats, or nullptr: keep only the last frame
+    float *last_frame = nullptr;      // width * height * 4 floats
+    unsigned char unique_id[SHRAY_DIST_UNIQUE_ID_BYTES];
+    shray_dist_hub *hub = nullptr;
+    std::vector<std::string> errors;
+    std::vector<double> seconds;      // per rank: the loop's wall time
+};
+
+void run_rank(multi_gpu_job *job, int rank)
+{
+    auto bail = [&](const char *what, const char *message) {
+        char buf[768];
+        snprintf(buf, sizeof(buf), "rank %d: %s: %s", rank, what, message);
+        job->errors[(size_t)rank] = buf;
+    };
+    const int device = job->transport == SHRAY_DIST_LOOPBACK ? 0 : rank;
+    shray_scene *scene = nullptr;
+    shray_dist *dist = nullptr;
+    if (shray_set_device(device) != SHRAY_OK || shray_scene_create(job->desc, &scene) != SHRAY_OK ||
+        shray_scene_set_environment(scene, job->env, job->env_w, job->env_h) != SHRAY_OK)
+        return bail("scene replica", shray_last_error());
+    shray_dist_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.rank = rank;
+    cfg.world = job->world;
+    cfg.width = job->width;
+    cfg.height = job->height;
+    cfg.spp = job->spp;
+    cfg.max_frames = std::min(job->world, SHRAY_MAX_BATCH);
+    cfg.root_mode = job->root_mode;
+    cfg.rgb_wire = 1;
+    cfg.transport = job->transport;
+    cfg.buffer_sets = 2;
+    const void *arg = job->transport == SHRAY_DIST_LOOPBACK ? (const void *)job->hub : (const void *)job->unique_id;
+    if (shray_dist_create(scene, &cfg, arg, &dist) != SHRAY_OK) {
+        bail("shray_dist_create", shray_dist_last_error());
+        shray_scene_destroy(scene);
+        return;
+    }
+    hipStream_t streams[2];
+    for (hipStream_t &st : streams)
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+            return bail("hipStreamCreate", "failed");
+    const size_t frame_floats = (size_t)job->width * job->height * 4;
+    const auto then = std::chrono::steady_clock::now();
+    // two steps in flight on two streams and two buffer sets: the exchange of one runs under the render of the next
+    int step = 0;
+    auto collect = [&](int which_step, int first_frame_of_step, int count) {
+        const int set = which_step % 2;
+        int assembled = 0, first = 0, stride = 1;
+        void *d_rgba = nullptr;
+        if (shray_dist_output(dist, set, count, &assembled, &first, &stride, &d_rgba) != SHRAY_OK)
+            return bail("shray_dist_output", shray_dist_last_error());
+        for (int k = 0; k < assembled; k++) {
+            const int frame = first_frame_of_step + first + k * stride;
+            float *dst = job->frames_out ? job->frames_out + (size_t)frame * frame_floats : (frame == job->frames - 1 ? job->last_frame : nullptr);
+            if (dst && hipMemcpyAsync(dst, (const char *)d_rgba + (size_t)k * frame_floats * 4, frame_floats * 4, hipMemcpyDeviceToHost,
+                                      streams[set]) != hipSuccess)
+                return bail("hipMemcpyAsync", "frame readback failed");
+        }
+    };
+    int pending_first = -1, pending_count = 0;
+    for (int f0 = 0; f0 < job->frames; f0 += cfg.max_frames, step++) {
+        const int count = std::min(cfg.max_frames, job->frames - f0);
+        if (step >= 2)
+            (void)hipStreamSynchronize(streams[step % 2]);   // the readbacks of the step that used this buffer set
+        if (shray_dist_step(dist, step % 2, job->params->data() + f0, count, streams[step % 2]) != SHRAY_OK) {
+            bail("shray_dist_step", shray_dist_last_error());
+            break;
+        }
+        if (pending_count)
+            collect(step - 1, pending_first, pending_count);
+        pending_first = f0;
+        pending_count = count;
+    }
+    if (pending_count && job->errors[(size_t)rank].empty())
+        collect(step - 1, pending_first, pending_count);
+    for (hipStream_t st : streams)
+        (void)hipStreamSynchronize(st);
+    job->seconds[(size_t)rank] = std::chrono::duration<double>(std::chrono::steady_clock::now() - then).count();
+    for (hipStream_t st : streams)
+        (void)hipStreamDestroy(st);
+    shray_dist_destroy(dist);
+    shray_scene_destroy(scene);
+}
+
+}   // namespace
 
 int main(int argc, char **argv)
 {
@@ -31,8 +141,8 @@ int main(int argc, char **argv)
                         "background color can be floats as \"r, g, b\", \"grid\", or hex as \"rrggbb\"\n", argv[0]);
         return EXIT_FAILURE;
     }
-    int width = 512, height = 512, material = 0, diffuse = 0, spp = 1, frames = 1;
-    std::string out = "color.ppm", dump_prefix;
+    int width = 512, height = 512, material = 0, diffuse = 0, spp = 1, frames = 1, gpus = 1;
+    std::string out = "color.ppm", dump_prefix, root_mode = "rotate", transport = "rccl";
     for (int i = 3; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "-o")) out = argv[i + 1];
         else if (!strcmp(argv[i], "-w")) width = atoi(argv[i + 1]);
@@ -42,6 +152,9 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-s")) spp = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-n")) frames = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-f")) dump_prefix = argv[i + 1];
+        else if (!strcmp(argv[i], "-g")) gpus = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "-r")) root_mode = argv[i + 1];
+        else if (!strcmp(argv[i], "-t")) transport = argv[i + 1];
     }
 
     world_ptr world = load_world(argv[1]);
@@ -73,53 +186,123 @@ int main(int argc, char **argv)
     desc.group_hitmiss = data.group_hitmiss;
     desc.group_objects = data.group_objects;
 
-    shray_scene *scene = nullptr;
-    if (shray_scene_create(&desc, &scene) != SHRAY_OK || shray_scene_set_environment(scene, env.data(), env_w, env_h) != SHRAY_OK) {
-        fprintf(stderr, "GPU setup failed: %s\n", shray_last_error());
-        return EXIT_FAILURE;
-    }
-
     view_state view = default_view_state(world);
     view.which_material = material;
     view.which_diffuse_color = diffuse;
     shray_frame_params params;
     make_frame_params(world, view, width, height, &params);
+    // the animation: what a user dragging the mouse does (MotionCallback, ray.cpp:879-918): the object for the first
+    // half of the run, the light ('l' key) for the second; 'm' every 25 frames
+    auto advance_view = [&](int frame) {
+        if (frames <= 1)
+            return;
+        float *target = (frame < frames / 2) ? view.object_rotation : view.light_rotation;
+        trackball_motion(target, 0.011f, 0.004f, target);
+        if (frame % 25 == 24)
+            view.which_material = (view.which_material + 1) % material_count;
+        make_frame_params(world, view, width, height, &params);
+    };
+    auto dump_frame = [&](int frame, const float *pixels) {
+        char name[1024];
+        snprintf(name, sizeof(name), "%s%03d.rgba", dump_prefix.c_str(), frame);
+        FILE *df = fopen(name, "wb");
+        if (!df || fwrite(pixels, 16, (size_t)width * height, df) != (size_t)width * height) {
+            fprintf(stderr, "cannot write %s\n", name);
+            return false;
+        }
+        fclose(df);
+        return true;
+    };
 
-    // the frame lands in pinned host memory: shray_render then reads it back with one DMA at PCIe speed
+    // the frame lands in pinned host memory: the readback is then one DMA at PCIe speed
     float *rgba = nullptr;
     if (shray_pinned_alloc((size_t)width * height * 16, (void **)&rgba) != SHRAY_OK) {
         fprintf(stderr, "pinned allocation failed: %s\n", shray_last_error());
         return EXIT_FAILURE;
     }
     std::vector<float> frame_seconds;
-    for (int frame = 0; frame < std::max(frames, 1); frame++) {
-        if (frames > 1) {
-            // what a user dragging the mouse does (MotionCallback, ray.cpp:879-918): the object for
-            // the first half of the run, the light ('l' key) for the second; 'm' every 25 frames
-            float *target = (frame < frames / 2) ? view.object_rotation : view.light_rotation;
-            trackball_motion(target, 0.011f, 0.004f, target);
-            if (frame % 25 == 24)
-                view.which_material = (view.which_material + 1) % material_count;
-            make_frame_params(world, view, width, height, &params);
+    shray_scene *scene = nullptr;
+    if (gpus > 1 || transport == "loopback") {
+        multi_gpu_job job;
+        job.world = gpus;
+        job.width = width;
+        job.height = height;
+        job.spp = spp;
+        job.frames = std::max(frames, 1);
+        job.root_mode = root_mode == "root0" ? SHRAY_DIST_ROOT0 : SHRAY_DIST_ROTATE;
+        job.transport = transport == "loopback" ? SHRAY_DIST_LOOPBACK : SHRAY_DIST_RCCL;
+        job.desc = &desc;
+        job.env = env.data();
+        job.env_w = env_w;
+        job.env_h = env_h;
+        std::vector<shray_frame_params> all;
+        for (int frame = 0; frame < job.frames; frame++) {
+            advance_view(frame);
+            all.push_back(params);
         }
-        const auto then = std::chrono::steady_clock::now();
-        if (shray_render(scene, &params, width, height, spp, rgba) != SHRAY_OK) {
-            fprintf(stderr, "render failed: %s\n", shray_last_error());
+        job.params = &all;
+        job.last_frame = rgba;
+        if (!dump_prefix.empty() &&
+            shray_pinned_alloc((size_t)job.frames * width * height * 16, (void **)&job.frames_out) != SHRAY_OK) {
+            fprintf(stderr, "pinned allocation failed: %s\n", shray_last_error());
             return EXIT_FAILURE;
         }
-        frame_seconds.push_back(std::chrono::duration<float>(std::chrono::steady_clock::now() - then).count());
-        if (!dump_prefix.empty()) {
-            char name[1024];
-            snprintf(name, sizeof(name), "%s%03d.rgba", dump_prefix.c_str(), frame);
-            FILE *df = fopen(name, "wb");
-            if (!df || fwrite(rgba, 16, (size_t)width * height, df) != (size_t)width * height) {
-                fprintf(stderr, "cannot write %s\n", name);
+        int devices = 0;
+        if (shray_device_count(&devices) != SHRAY_OK || (job.transport == SHRAY_DIST_RCCL && devices < gpus)) {
+            fprintf(stderr, "-g %d over RCCL needs %d GPUs, %d visible (-t loopback shares GPU 0)\n", gpus, gpus, devices);
+            return EXIT_FAILURE;
+        }
+        if (job.transport == SHRAY_DIST_RCCL ? shray_dist_unique_id(job.unique_id) != SHRAY_OK
+                                             : shray_dist_hub_create(gpus, &job.hub) != SHRAY_OK) {
+            fprintf(stderr, "transport setup failed: %s\n", shray_dist_last_error());
+            return EXIT_FAILURE;
+        }
+        job.errors.assign((size_t)gpus, std::string());
+        job.seconds.assign((size_t)gpus, 0.0);
+        std::vector<std::thread> ranks;
+        for (int r = 0; r < gpus; r++)
+            ranks.emplace_back(run_rank, &job, r);
+        for (std::thread &t : ranks)
+            t.join();
+        if (job.hub)
+            shray_dist_hub_destroy(job.hub);
+        for (const std::string &e : job.errors)
+            if (!e.empty()) {
+                fprintf(stderr, "%s\n", e.c_str());
                 return EXIT_FAILURE;
             }
-            fclose(df);
+        const double slowest = *std::max_element(job.seconds.begin(), job.seconds.end());
+        printf("%d frames on %d GPUs (%s, %s): %.3f ms per frame, %.1f Mrays/s\n", job.frames, gpus,
+               job.root_mode == SHRAY_DIST_ROOT0 ? "root0" : "rotating roots", job.transport == SHRAY_DIST_RCCL ? "rccl" : "loopback",
+               slowest / job.frames * 1e3, (double)width * height * spp * job.frames / slowest / 1e6);
+        if (job.frames_out) {
+            for (int frame = 0; frame < job.frames; frame++)
+                if (!dump_frame(frame, job.frames_out + (size_t)frame * width * height * 4))
+                    return EXIT_FAILURE;
+            memcpy(rgba, job.frames_out + (size_t)(job.frames - 1) * width * height * 4, (size_t)width * height * 16);
+            shray_pinned_free(job.frames_out);
+        }
+        frames = 0;   // no per-frame histogram: the loop's rate is printed above
+    } else {
+        if (shray_scene_create(&desc, &scene) != SHRAY_OK || shray_scene_set_environment(scene, env.data(), env_w, env_h) != SHRAY_OK) {
+            fprintf(stderr, "GPU setup failed: %s\n", shray_last_error());
+            return EXIT_FAILURE;
+        }
+        for (int frame = 0; frame < std::max(frames, 1); frame++) {
+            advance_view(frame);
+            const auto then = std::chrono::steady_clock::now();
+            if (shray_render(scene, &params, width, height, spp, rgba) != SHRAY_OK) {
+                fprintf(stderr, "render failed: %s\n", shray_last_error());
+                return EXIT_FAILURE;
+            }
+            frame_seconds.push_back(std::chrono::duration<float>(std::chrono::steady_clock::now() - then).count());
+            if (!dump_prefix.empty() && !dump_frame(frame, rgba))
+                return EXIT_FAILURE;
         }
     }
-    if (frames <= 1) {
+    if (frames == 0) {
+        // (multi-GPU run: reported above)
+    } else if (frames <= 1) {
         fprintf(stderr, "%dx%d, %d spp: %.3f ms including the copy to host\n", width, height, spp, frame_seconds[0] * 1e3);
     } else {
         // the reference's benchmark print-out (ray.cpp:1116-1131)

@@ -34,6 +34,21 @@ def test_host_library_exports_every_declared_symbol(pkg):
     assert sorted(n for n, _, _ in pkg._native.HOST_SYMBOLS) == names
 
 
+def test_dist_library_exports_every_declared_symbol(pkg):
+    lib = pkg._native.load_dist()
+    names = declared_functions("shader_ray_dist.h")
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(lib, name), f"libshray_dist.so does not export {name}"
+    assert sorted(n for n, _, _ in pkg._native.DIST_SYMBOLS) == names
+
+
+def test_abi_version_matches_the_header(pkg):
+    text = open(os.path.join(ROOT, "include", "shader_ray_hip.h")).read()
+    declared = int(re.search(r"#define SHRAY_ABI_VERSION (\d+)", text).group(1))
+    assert pkg._native.ABI_VERSION == declared == pkg._native.load_hip().shray_abi_version()
+
+
 def test_struct_layouts_match_the_headers(pkg, tmp_path):
     """Compiles a tiny C program against the headers and compares sizeof/offsetof."""
     import subprocess
@@ -43,9 +58,12 @@ def test_struct_layouts_match_the_headers(pkg, tmp_path):
 #include <stddef.h>
 #include "shader_ray_hip.h"
 #include "shader_ray_host.h"
+#include "shader_ray_dist.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(shray_scene_desc), sizeof(shray_frame_params), sizeof(shray_tile_set),
          sizeof(shray_counters), sizeof(shray_host_view), sizeof(shray_host_world_info));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(shray_dist_config), sizeof(shray_dist_xfer), sizeof(shray_dist_plan),
+         sizeof(shray_dist_callbacks), offsetof(shray_dist_plan, owned_tiles), offsetof(shray_dist_config, transport));
   printf("%zu %zu %zu %zu\n", offsetof(shray_scene_desc, group_hitmiss), offsetof(shray_frame_params, image_plane_width),
          offsetof(shray_frame_params, bounce_count), offsetof(shray_host_view, which_material));
   return 0; }''')
@@ -55,6 +73,8 @@ int main(void) {
     N = pkg._native
     want = [C.sizeof(N.SceneDesc), C.sizeof(N.FrameParams), C.sizeof(N.TileSet), C.sizeof(N.Counters),
             C.sizeof(N.HostView), C.sizeof(N.HostWorldInfo),
+            C.sizeof(N.DistConfig), C.sizeof(N.DistXfer), C.sizeof(N.DistPlan), C.sizeof(N.DistCallbacks),
+            N.DistPlan.owned_tiles.offset, N.DistConfig.transport.offset,
             N.SceneDesc.group_hitmiss.offset, N.FrameParams.image_plane_width.offset,
             N.FrameParams.bounce_count.offset, N.HostView.which_material.offset]
     assert [int(x) for x in out] == want

@@ -1,0 +1,217 @@
+"""The multi-GPU frame loop through its C ABI (include/shader_ray_dist.h) on ONE MI355X.
+
+RCCL refuses two ranks on one device, so the N-rank step is rehearsed with the LOOPBACK transport: the ranks are
+threads of this process, each with its own scene replica, HIP stream and shray_dist object, all on device 0, and the
+tile buffers travel through the in-process hub.  Everything else is the product path: shray_render_batch_device on
+the rank's tile set, the pack kernel, the transfer lists of the plan, shray_assemble_tiles_split_device.  Every
+assembled frame must equal a single full-frame render bit for bit, in both root modes.  The RCCL transport itself is
+exercised with one rank (communicator creation, a step without peers); a two-process gloo run covers the CALLBACK
+transport and with it bench.py's rehearsal path."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ranks(pkg, world_file, env, W, H, spp, ranks, frames, mode, shares, rgb, steps, materials):
+    """`steps` steps of `frames` frames on `ranks` loopback ranks; returns {(step, frame): [H, W, 4] array}."""
+    import torch
+    from shader_ray_amd import multigpu
+    hub = multigpu.Hub(ranks)
+    world = pkg.World(world_file)
+    desc = world.flatten()
+    params = [[world.frame_params(W, H, material=materials[(s * frames + f) % len(materials)]) for f in range(frames)] for s in range(steps)]
+    got, errors = {}, []
+    lock = threading.Lock()
+    barrier = threading.Barrier(ranks)
+
+    def body(rank):
+        try:
+            torch.cuda.set_device(0)
+            scene = pkg.Scene(desc, env, device=0)
+            cfg = multigpu.make_config(rank, ranks, W, H, spp, frames, mode, multigpu.LOOPBACK, shares, 32, 32, rgb, buffer_sets=2)
+            me = multigpu.Rank(scene, cfg, hub)
+            streams = [torch.cuda.Stream(device=0) for _ in range(2)]
+            barrier.wait()
+            mine = {}
+            for s in range(steps):
+                count = frames if s + 1 < steps or frames == 1 else frames - 1     # the last step is short
+                me.step(params[s][:count], s % 2, streams[s % 2].cuda_stream)
+                # frames are fetched a step late: the next step is already enqueued on the other stream / buffer set
+                if s > 0:
+                    prev = frames
+                    for f, t in me.frames((s - 1) % 2, prev, streams[(s - 1) % 2].cuda_stream).items():
+                        mine[(s - 1, f)] = t
+            last = frames if steps == 1 or frames == 1 else frames - 1
+            for f, t in me.frames((steps - 1) % 2, last, streams[(steps - 1) % 2].cuda_stream).items():
+                mine[(steps - 1, f)] = t
+            torch.cuda.synchronize()
+            with lock:
+                for k, t in mine.items():
+                    assert k not in got, f"frame {k} assembled twice"
+                    got[k] = t.cpu().numpy()
+            barrier.wait()
+            me.close()
+            scene.close()
+        except Exception as exc:   # noqa: BLE001
+            errors.append((rank, repr(exc)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    hub.close()
+    assert not errors, errors
+    return got, params
+
+
+@pytest.mark.parametrize("ranks,frames,mode,shares,rgb", [
+    (2, 1, "root0", None, True), (3, 2, "root0", (2, 3), True), (8, 8, "root0", None, True), (4, 3, "root0", (1, 1), False),
+    (2, 2, "rotate", None, True), (3, 3, "rotate", None, False), (8, 8, "rotate", None, True), (3, 7, "rotate", None, True),
+    (4, 2, "rotate", None, True)])
+def test_loopback_ranks_assemble_the_full_frames(pkg, gpu, ranks, frames, mode, shares, rgb):
+    from shader_ray_amd import multigpu
+    W, H, spp = 333, 200, 2
+    env = pkg.scenes.environment_hdr_sky(128)
+    path = os.path.join(GOLDEN, "lobed_528.trisrc")
+    steps = 3
+    got, params = run_ranks(pkg, path, env, W, H, spp, ranks, frames, multigpu.ROTATE if mode == "rotate" else multigpu.ROOT0,
+                            shares, rgb, steps, materials=(0, 6, 3))
+    scene = pkg.Scene(pkg.World(path).flatten(), env, device=0)
+    expected = set()
+    for s in range(steps):
+        count = frames if s + 1 < steps or frames == 1 else frames - 1
+        for f in range(count):
+            expected.add((s, f))
+            want = scene.render(params[s][f], W, H, spp)
+            assert np.array_equal(got[(s, f)].view(np.uint32), want.view(np.uint32)), (ranks, frames, mode, s, f)
+    assert set(got) == expected
+    scene.close()
+
+
+def test_config5_shape_on_eight_loopback_ranks(pkg, gpu):
+    """BASELINE configs[4] scaled to a quarter of the pixels: 1920x1080, 16 spp, eight ranks, both root modes."""
+    import helpers
+    from shader_ray_amd import multigpu
+    env = pkg.scenes.environment_hdr_sky(256)
+    path = helpers.bunny_trisrc()
+    scene = pkg.Scene(pkg.World(path).flatten(), env, device=0)
+    for mode in (multigpu.ROOT0, multigpu.ROTATE):
+        got, params = run_ranks(pkg, path, env, 1920, 1080, 16, 8, 8 if mode == multigpu.ROTATE else 2, mode, None, True, 1, materials=(0, 6))
+        for (s, f), frame in got.items():
+            want = scene.render(params[s][f], 1920, 1080, 16)
+            assert np.array_equal(frame.view(np.uint32), want.view(np.uint32)), (mode, f)
+        assert len(got) == (8 if mode == multigpu.ROTATE else 2)
+    scene.close()
+
+
+def test_rccl_transport_with_one_rank(pkg, gpu):
+    """ncclGetUniqueId / ncclCommInitRank behind shray_dist_create, and a step that has no peers."""
+    import torch
+    from shader_ray_amd import multigpu
+    W, H = 200, 136
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(128), device=0)
+    uid = multigpu.unique_id()
+    assert len(uid) == 128 and any(uid)
+    for mode in (multigpu.ROOT0, multigpu.ROTATE):
+        cfg = multigpu.make_config(0, 1, W, H, 1, 3, mode, multigpu.RCCL)
+        me = multigpu.Rank(scene, cfg, uid)
+        params = [world.frame_params(W, H, material=m) for m in (0, 6, 2)]
+        me.step(params, 0, torch.cuda.current_stream().cuda_stream)
+        frames = me.frames(0, 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert sorted(frames) == [0, 1, 2]
+        for f, t in frames.items():
+            assert np.array_equal(t.cpu().numpy(), scene.render(params[f], W, H, 1))
+        me.close()
+    N = pkg._native
+    with pytest.raises(N.ShrayError):
+        multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 65), uid)          # more frames than SHRAY_MAX_BATCH
+    me = multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 2), uid)
+    with pytest.raises(N.ShrayError):
+        me.step([world.frame_params(W, H)] * 3, 0, 0)                                # more frames than the object was made for
+    with pytest.raises(N.ShrayError):
+        me.step([world.frame_params(W, H)], 5, 0)                                    # no such buffer set
+    me.close()
+    scene.close()
+
+
+def _gloo_worker(rank, world_size, port, mode, out_path):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from shader_ray_amd import multigpu
+    torch.cuda.set_device(0)
+    W, H = 200, 136
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(128), device=0)
+    frames = 2
+    cfg = multigpu.make_config(rank, world_size, W, H, 1, frames, mode, multigpu.CALLBACK)
+    me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
+    params = [world.frame_params(W, H, material=m) for m in (0, 6)]
+    stream = torch.cuda.current_stream().cuda_stream
+    me.step(params, 0, stream)
+    mine = me.frames(0, frames, stream)
+    torch.cuda.synchronize()
+    ok = all(np.array_equal(t.cpu().numpy(), scene.render(params[f], W, H, 1)) for f, t in mine.items())
+    everyone = [None] * world_size
+    dist.all_gather_object(everyone, (sorted(mine), ok))
+    if rank == 0:
+        np.save(out_path, np.asarray([int(all(o for _, o in everyone)), sum(len(k) for k, _ in everyone)]))
+    dist.barrier()
+    me.close()
+    scene.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["root0", "rotate"])
+def test_callback_transport_over_gloo_two_processes(pkg, gpu, tmp_path, mode):
+    """Two processes share the GPU; the tile buffers travel through host memory with gloo (multigpu.HostExchange),
+    driven by the C library's CALLBACK transport -- the path bench.py's one-GPU rehearsal takes."""
+    import torch.multiprocessing as mp
+    from shader_ray_amd import multigpu
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_gloo_worker, args=(2, port, multigpu.ROTATE if mode == "rotate" else multigpu.ROOT0, out), nprocs=2, join=True)
+    ok, frames = np.load(out)
+    assert ok == 1 and frames == 2
+
+
+@pytest.mark.parametrize("ranks,root", [(3, "rotate"), (4, "root0"), (8, "rotate")])
+def test_command_line_harness_on_several_ranks(pkg, gpu, tmp_path, ranks, root):
+    """`shray_render -g N -t loopback -n frames`: the C++ frame loop (one thread per rank, steps of N frames, two buffer
+    sets in flight) renders the same trackball animation as the single-GPU loop, frame for frame, and saves the last one."""
+    import subprocess
+    exe = os.path.join(ROOT, "shader-ray_amd", "tools", "shray_render")
+    model = os.path.join(GOLDEN, "lobed_528.trisrc")
+    W, H, frames = 160, 96, 2 * ranks + 3
+    single, multi = str(tmp_path / "one"), str(tmp_path / "many")
+    common = [exe, model, "grid", "-w", str(W), "-h", str(H), "-n", str(frames), "-s", "2"]
+    subprocess.run(common + ["-o", single + ".ppm", "-f", single], check=True, capture_output=True, text=True)
+    run = subprocess.run(common + ["-o", multi + ".ppm", "-f", multi, "-g", str(ranks), "-t", "loopback", "-r", root],
+                         check=True, capture_output=True, text=True)
+    assert f"{frames} frames on {ranks} GPUs" in run.stdout and "Mrays/s" in run.stdout, run.stdout
+    for frame in range(frames):
+        a = np.fromfile(f"{single}{frame:03d}.rgba", dtype=np.float32)
+        b = np.fromfile(f"{multi}{frame:03d}.rgba", dtype=np.float32)
+        assert a.size == W * H * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), frame
+    assert open(single + ".ppm", "rb").read() == open(multi + ".ppm", "rb").read()
+    # without -f only the last frame is read back
+    subprocess.run(common + ["-o", multi + "2.ppm", "-g", str(ranks), "-t", "loopback", "-r", root], check=True, capture_output=True)
+    assert open(single + ".ppm", "rb").read() == open(multi + "2.ppm", "rb").read()

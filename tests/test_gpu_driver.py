@@ -180,7 +180,8 @@ def test_uneven_rank_shares_on_one_gpu(pkg, gpu):
         for k in range(2):
             assert np.array_equal(out[k].cpu().numpy(), want[k]), (W, H, tile, ranks, shares, k)
     # the object the bench uses, one rank: shares collapse to (1, 1)
-    assert multigpu.DistributedFrame(64, 64, 32, 32, device="cuda:0").shares == (1, 1)
+    one = multigpu.plan(multigpu.make_config(0, 1, 64, 64))
+    assert (one.rank0_phases, one.other_phases) == (1, 1)
     with pytest.raises(N.ShrayError):
         scene.render_into(world.frame_params(64, 64), 64, 64, 1, out.data_ptr(), stream, N.TileSet(32, 32, 4, 3, 2))
     scene.close()

@@ -368,31 +368,6 @@ def test_frame_batches_equal_single_launches(pkg, gpu, bunny):
     assert np.array_equal(one[: nbytes // 4].cpu().numpy().reshape(H, W, 4), scene.render(mixed, W, H, 1))
 
 
-@pytest.mark.parametrize("rgb_wire", [True, False])
-def test_split_frame_object_on_one_gpu(pkg, gpu, bunny, rgb_wire):
-    """multigpu.DistributedFrame without a process group (one rank owns every tile): one launch for two
-    frames, pack, de-interleave kernel -- the frames must be those of direct full-frame renders."""
-    import torch
-    from shader_ray_amd import multigpu
-    world, desc, scene = bunny
-    W, H = 200, 136
-    frames = [world.frame_params(W, H, material=m) for m in (0, 6)]
-    split = multigpu.DistributedFrame(W, H, 32, 32, device="cuda:0", frames=2, rgb_wire=rgb_wire)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def render_tiles(tile_set, out):
-        scene.render_batch_into(frames[: out.shape[0]], W, H, 1, out.data_ptr(), split.frame_stride_bytes, stream, tile_set)
-
-    got = split.render(render_tiles)
-    torch.cuda.synchronize()
-    assert got.shape == (2, H, W, 4)
-    for k in range(2):
-        assert np.array_equal(got[k].cpu().numpy(), scene.render(frames[k], W, H, 1)), k
-    short = split.render(render_tiles, count=1)
-    torch.cuda.synchronize()
-    assert short.shape == (1, H, W, 4) and np.array_equal(short[0].cpu().numpy(), scene.render(frames[0], W, H, 1))
-
-
 def test_error_paths(pkg, gpu, bunny, env_sky):
     N = pkg._native
     world, desc, scene = bunny
@@ -617,7 +592,7 @@ def test_config5_4k_16spp_eight_way_tile_split(pkg, gpu, bunny):
     """BASELINE config 5's frame (3840x2160, 16 spp) split into the eight interleaved tile sets the
     eight GPUs would own: the packed tile buffers reassemble to the single-GPU frame bit for bit."""
     import torch
-    from shader_ray_amd.multigpu import assemble_tiles_torch, max_tiles_per_rank
+    from shader_ray_amd.multigpu import max_tiles_per_rank
     world, desc, scene = bunny
     W, H, spp, tile, ranks = 3840, 2160, 16, 32, 8
     params = world.frame_params(W, H, material=0)
@@ -629,9 +604,12 @@ def test_config5_4k_16spp_eight_way_tile_split(pkg, gpu, bunny):
     N = pkg._native
     for r in range(ranks):
         scene.render_into(params, W, H, spp, gathered[r].data_ptr(), stream, N.TileSet(tile, tile, ranks, r))
-    frame = assemble_tiles_torch(gathered.view(ranks, per_rank, tile, tile, 4), W, H, tile, tile)
+    frame = torch.empty(H * W * 4, dtype=torch.float32, device="cuda:0")
+    N.check(N.load_hip().shray_assemble_tiles_device(
+        C.c_void_p(gathered.data_ptr()), ranks, 1, 4, gathered.stride(0) * 4, gathered.stride(0) * 4, W, H, tile, tile,
+        C.c_void_p(frame.data_ptr()), C.c_void_p(stream)))
     torch.cuda.synchronize()
-    assert torch.equal(frame.reshape(-1), full)
+    assert torch.equal(frame, full)
 
 
 @pytest.mark.parametrize("material", [0, 6])

@@ -291,6 +291,18 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params,
                           float *rgba_out_host /* may be NULL */,
                           shray_counters *counters);
 
+/* The counters above are those of the reference's traversal: the counting kernels walk every shadow ray to its end
+ * (raytracer.es.fs:447-472 does), so that they can be compared with the CPU evaluation node for node.  The kernels
+ * that shray_render / shray_render_batch_device actually launch stop a shadow ray at its first hit (the shader only
+ * asks whether anything is hit, fs:516-521) and run a pixel's samples in neighbouring lanes; this entry point
+ * renders the frame with THAT instance -- the one a launch of frames_per_launch such frames would select -- and
+ * returns ITS tallies: equal to the reference's for metals (no shadow rays), smaller for diffuse materials; the
+ * image is the same either way.  bad_hits counts primary / bounce samples that returned the iteration-cap marker. */
+int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *params,
+                                int width, int height, int spp, int frames_per_launch,
+                                float *rgba_out_host /* may be NULL */,
+                                shray_counters *counters);
+
 /* Self-test ---------------------------------------------------------------- */
 /* Runs the kernel's 5-instruction "divide by a per-ray constant" (csrc/exact_div.h)
  * against true IEEE division on `pairs` pseudo-random operand pairs from the operand

@@ -123,6 +123,8 @@ HIP_SYMBOLS = [
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("shray_render_counters", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                         c_float_p, C.POINTER(Counters)]),
+    ("shray_render_counters_timed", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
+                                              c_float_p, C.POINTER(Counters)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
 ]
 

@@ -445,8 +445,10 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 // The stack kernel reads its FrameViews from device memory (far fewer scalar registers held, and
 // spilled, than with the 480-byte view as a by-value kernel argument): `count` views travel through a
 // ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
+// tally / policy_frames: shray_render_counters_timed -- the instance a launch of `policy_frames` frames would run, with
+// per-ray work tallies
 int launch_stack_views(shray_scene *scene, const FrameView *views, int count, float4 *d_out, size_t frame_stride,
-                       hipStream_t stream)
+                       hipStream_t stream, DeviceCounters *tally = nullptr, int policy_frames = 0)
 {
     if (views[0].total_patches == 0)
         return SHRAY_OK;
@@ -472,10 +474,11 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
     bool plain_view = true;   // the pool kernel renders which == 0 frames; the shader's debug views stay on the stack kernel
     for (int k = 0; k < count; k++)
         plain_view = plain_view && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
-    const hipError_t e = (scene->kernel_id == 2 && plain_view)
+    const hipError_t e = (scene->kernel_id == 2 && plain_view && !tally)
         ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
         : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
-                             leaf_stage_policy(scene, count, views[0].spp), d_out, frame_stride, stream, scene->stack_levels);
+                             leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp), d_out, frame_stride, stream,
+                             scene->stack_levels, tally);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
@@ -981,6 +984,54 @@ int shray_render_counters(shray_scene *scene, const shray_frame_params *params, 
     counters->traversals = dc.traversals;
     counters->bad_hits = dc.bad_hits;
     counters->samples = (uint64_t)width * height * spp;
+    return SHRAY_OK;
+}
+
+int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *params, int width, int height, int spp,
+                                int frames_per_launch, float *rgba_out_host, shray_counters *counters)
+{
+    if (!scene || !counters)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene or counters is NULL");
+    int rc = validate_params(params, width, height, spp);
+    if (rc)
+        return rc;
+    if (frames_per_launch < 1 || frames_per_launch > SHRAY_MAX_BATCH)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "frames_per_launch %d (1..%d)", frames_per_launch, SHRAY_MAX_BATCH);
+    const bool view = params->which == 1 || params->which == 2 || params->which == 3 || params->which == 5;
+    // only the stack kernel's convergent instances have a timed form of their own; everything else is timed as it counts
+    if (scene->kernel_id != 0 || !scene->packed_ok || view || scene->patch_order.p)
+        return shray_render_counters(scene, params, width, height, spp, rgba_out_host, counters);
+    if (!scene->view.env)
+        return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");
+    HIP_TRY(hipSetDevice(scene->device));
+    FrameView fr;
+    rc = make_frame_view(params, width, height, spp, nullptr, &fr);
+    if (rc)
+        return rc;
+    DeviceBuffer frame;
+    const size_t bytes = (size_t)width * height * 16;
+    HIP_TRY(frame.upload(nullptr, bytes));
+    HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(DeviceCounters) * kCounterShards));
+    HIP_TRY(hipDeviceSynchronize());
+    rc = launch_stack_views(scene, &fr, 1, (float4 *)frame.p, 0, nullptr, (DeviceCounters *)scene->counters.p, frames_per_launch);
+    if (rc)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    DeviceCounters shards[kCounterShards];
+    HIP_TRY(hipMemcpy(shards, scene->counters.p, sizeof(shards), hipMemcpyDeviceToHost));
+    memset(counters, 0, sizeof(*counters));
+    for (const DeviceCounters &sh : shards) {
+        counters->node_visits += sh.node_visits;
+        counters->leaf_visits += sh.leaf_visits;
+        counters->triangle_tests += sh.triangle_tests;
+        counters->shaded_hits += sh.shaded_hits;
+        counters->env_lookups += sh.env_lookups;
+        counters->traversals += sh.traversals;
+        counters->bad_hits += sh.bad_hits;
+    }
+    counters->samples = (uint64_t)width * height * spp;
+    if (rgba_out_host)
+        HIP_TRY(hipMemcpy(rgba_out_host, frame.p, bytes, hipMemcpyDeviceToHost));
     return SHRAY_OK;
 }
 

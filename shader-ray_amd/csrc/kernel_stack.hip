@@ -116,10 +116,9 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // Batch forms: workgroup (x, y) renders patch x of frame y.  Workgroups are dispatched x-fastest, so
 // frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
 // DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
-template <bool ONE_SAMPLE, bool METAL, bool DEAL>
-__global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
-                                                                                               float4 *out, size_t frame_stride, int stack_levels,
-                                                                                               int frame_count_arg)
+template <bool ONE_SAMPLE, bool METAL, bool DEAL, bool TALLY>
+__device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,
+                                                 int stack_levels, int frame_count_arg, DeviceCounters *counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     StackTraversal<kBatchBlock, DEAL> trav = make_traversal<DEAL, kBatchBlock>(lds_stack, stack_levels, sc);
@@ -136,12 +135,31 @@ __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE
         frame = rest % frame_count;
         block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
     }
-    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[frame], out + (size_t)frame * frame_stride,
-                                                                                     nullptr, trav, block_index);
+    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, TALLY, ONE_SAMPLE, METAL, TALLY>(sc, frames[frame], out + (size_t)frame * frame_stride,
+                                                                                            counters, trav, block_index);
 #else
-    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, false, ONE_SAMPLE, METAL>(sc, frames[blockIdx.y],
-                                                                                     out + (size_t)blockIdx.y * frame_stride, nullptr, trav);
+    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, TALLY, ONE_SAMPLE, METAL, TALLY>(sc, frames[blockIdx.y],
+                                                                                            out + (size_t)blockIdx.y * frame_stride, counters, trav);
 #endif
+}
+
+template <bool ONE_SAMPLE, bool METAL, bool DEAL>
+__global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE)) trace_stack_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+                                                                                               float4 *out, size_t frame_stride, int stack_levels,
+                                                                                               int frame_count_arg)
+{
+    stack_batch_body<ONE_SAMPLE, METAL, DEAL, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+}
+
+// The same instances with per-ray work tallies (shray_render_counters_timed): what the TIMED form does -- sample lanes,
+// shadow rays that stop at their first hit -- as opposed to the counting twins of trace_stack_kernel, which reproduce
+// the reference's full traversals.  Never timed.
+template <bool ONE_SAMPLE, bool METAL, bool DEAL>
+__global__ void __launch_bounds__(kBatchBlock, 4) trace_stack_batch_tally_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out,
+                                                                                 size_t frame_stride, int stack_levels, int frame_count_arg,
+                                                                                 DeviceCounters *counters)
+{
+    stack_batch_body<ONE_SAMPLE, METAL, DEAL, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, counters);
 }
 
 template <bool DIFF>
@@ -162,7 +180,8 @@ static size_t stack_lds_bytes(int stack_levels, int block = kBlock)
 // `all_metal`: every frame of the batch has a zero diffuse colour; `all_plain`: every frame has which == 0;
 // `deal`: the dealt leaf stage instead of the plain one (capi.hip: leaf_stage_policy)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
-                              bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels)
+                              bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
+                              DeviceCounters *tally)
 {
     // the view instances run 256-thread workgroups (a patch each), the convergent ones kBatchBlock-thread workgroups
     const bool view_instance = !all_plain;
@@ -181,6 +200,29 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     const bool one = SHRAY_SPECIALIZE && one_sample(first), metallic = SHRAY_SPECIALIZE && all_metal;
 #define SHRAY_LAUNCH_VIEW_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
 #define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels, count)
+#define SHRAY_LAUNCH_TALLY(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels, count, tally)
+    if (tally && all_plain) {   // the same choice of instance as below, with tallies
+        if (one && metallic && deal)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, true, true>));
+        else if (one && metallic)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, true, false>));
+#if SHRAY_GENERAL_PLAIN
+        else if (one && !deal)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, false, false>));
+        else if (!one && !metallic && !deal)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<false, false, false>));
+#endif
+        else if (one)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, false, true>));
+        else if (metallic && deal)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<false, true, true>));
+        else if (metallic)
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<false, true, false>));
+        else
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<false, false, true>));
+        return hipGetLastError();
+    }
+#undef SHRAY_LAUNCH_TALLY
     if (!all_plain && (first.which == 1 || first.which == 2))
         SHRAY_LAUNCH_VIEW_BATCH(trace_stack_view_batch_kernel<true>);
     else if (!all_plain)

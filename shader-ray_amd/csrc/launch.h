@@ -23,8 +23,11 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 // all_metal: every frame's diffuse colour is zero (selects the kernel instance without the diffuse branch)
 // all_plain: every frame is a plain which == 0 frame (the convergent driver applies); deal: the instances that deal
 // leaf triangles to idle lanes (wave_traversal.h) instead of the plain leaf loop
+// tally: nullptr for the timed launches; else the same instance with per-ray work tallies added into `tally`
+// (kCounterShards copies) -- what the timed form does (shray_render_counters_timed)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
-                              bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
+                              bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
+                              DeviceCounters *tally = nullptr);
 
 // kernel id 2 (kernel_pool.hip): the workgroup's rays as a pool whose waves merge during the traversal;
 // which == 0 frames only.  Same argument conventions as the stack kernel's launchers.

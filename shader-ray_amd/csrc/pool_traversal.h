@@ -61,7 +61,7 @@ struct PoolTraversal {
     // Collective: every thread of the workgroup calls it (has_ray = this thread's pixel has a ray to trace).
     // Returns the number of rays the workgroup traced (uniform); `hit` is set for has_ray threads.
     // (ANY_HIT: accepted for the driver's shadow rays; this kernel walks them to the end)
-    template <bool COUNT, bool ANY_HIT = false>
+    template <bool COUNT, bool ANY_HIT = false, bool TIMED_FORM = false>
     __device__ __forceinline__ int closest(const SceneView &sc, const FrameView &fr, bool has_ray, V3 P, V3 D, Hit &hit,
                                            RayCounters &rc)
     {

@@ -55,8 +55,9 @@ struct StackTraversal {
     // ANY_HIT (shadow rays of the timed kernels, uniform_driver.h): the caller only asks whether hit.t stays at
     // "infinitely far" (fs:516-521: lit = shadow.t >= far).  Once a leaf has produced a hit the answer is "no" whatever
     // the rest of the walk finds -- a closer hit, or the iteration cap's bad hit (t = -1) -- so the ray stops there.
-    // The counting twins walk on: their tallies are compared with the reference's full traversal.
-    template <bool COUNT, bool ANY_HIT = false>
+    // The counting twins walk on: their tallies are compared with the reference's full traversal -- unless they are
+    // asked for the tallies of the timed form itself (TIMED_FORM).
+    template <bool COUNT, bool ANY_HIT = false, bool TIMED_FORM = false>
     __device__ __forceinline__ int closest(const SceneView &sc, const FrameView &fr, bool has_ray, V3 P, V3 D, Hit &hit,
                                            RayCounters &rc)
     {
@@ -66,7 +67,7 @@ struct StackTraversal {
         LaneTraversal t;
         lane_begin<COUNT>(sc, fr, t, stack, P, D, rc, has_ray);
         int state = has_ray ? LT_WALK : LT_ENDED;
-        run<COUNT, true, ANY_HIT && !COUNT>(sc, fr, t, state, rc);
+        run<COUNT, true, ANY_HIT && (!COUNT || TIMED_FORM)>(sc, fr, t, state, rc);
         hit = t.hit;
         return traced;
     }

@@ -232,6 +232,27 @@ __device__ __forceinline__ float filmic(float c)
     return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
 }
 
+// intersect_and_shade's tail for a valid hit (fs:503-521 with shade, fs:362-377, ray_transfer + ray_reflect, fs:65-96,
+// f_schlick_vr, fs:479-482): the facing normal, the reflected ray and the Fresnel-weighted specular colour.
+// (profiles/isa_costs.py counts it in isolation.)
+struct ShadedHit {
+    V3 n, R, P2, object_specular;
+};
+__device__ __forceinline__ ShadedHit shade_hit(const SceneView &sc, const FrameView &fr, V3 spec, V3 P, V3 D, const Hit &hit)
+{
+    ShadedHit s;
+    const V3 object_normal = interpolated_normal(sc, fr.normals_fp16 != 0, hit.which, hit.bu, hit.bv);
+    s.n = xform(fr.object_normal_inverse, object_normal, 0.0f);
+    if (dot3(s.n, D) > 0.0f)
+        s.n = s.n * -1.0f;
+    const V3 at = P + D * hit.t;                      // ray_transfer, fs:69
+    s.R = D - s.n * (2.0f * dot3(s.n, D));            // reflect(), fs:86
+    s.P2 = at + s.n * .0001f;                         // surface fudge, fs:87
+    const float fresnel = pow5(dot3(D, s.R) * .5f + .5f);
+    s.object_specular = spec + (mk(1.0f, 1.0f, 1.0f) - spec) * fresnel;   // f_schlick_vr, fs:479-482
+    return s;
+}
+
 // Ray differentials of fs:58-63, carried only by the which == 2 view.
 struct Differentials {
     V3 dPdx, dDdx, dPdy, dDdy;

@@ -26,7 +26,11 @@ namespace shray {
 #define SHRAY_SHADOW_ANY_HIT 1
 #endif
 
-template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL>
+// COUNT: tally per-ray work.  The counting twins walk every shadow ray to its end and run one lane per pixel, so that
+// their tallies equal the reference's full traversals (the oracle's); with TIMED_FORM they keep the timed instances'
+// form instead -- sample lanes, shadow rays that stop at their first hit -- and tally what THOSE do
+// (shray_render_counters_timed).
+template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool,
                                                      unsigned int block_index = 0xffffffffu)   // default: blockIdx.x
@@ -43,7 +47,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     bool store, inside;
     // lanes per pixel (multi-sample frames in one-wave workgroups only): G = gx * gy, this lane runs samples
     // sub, sub + G, ... of its pixel; base_lane = the pixel's lane with sub == 0
-    const bool sample_lanes = !ONE_SAMPLE && !COUNT && Traversal::block_size == 64;
+    const bool sample_lanes = !ONE_SAMPLE && (!COUNT || TIMED_FORM) && Traversal::block_size == 64;
     const unsigned int log_gx = sample_lanes ? fr.sample_log_x : 0u, log_gy = sample_lanes ? fr.sample_log_y : 0u;
     const unsigned int G = 1u << (log_gx + log_gy);
     unsigned int sub = 0, base_lane = threadIdx.x & 63u;
@@ -120,21 +124,17 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             if (shade) {
                 if (COUNT)
                     rc.shaded_hits++;
-                const V3 object_normal = interpolated_normal(sc, fr.normals_fp16 != 0, hit.which, hit.bu, hit.bv);
-                n = xform(fr.object_normal_inverse, object_normal, 0.0f);
-                if (dot3(n, D) > 0.0f)
-                    n = n * -1.0f;
-                const V3 at = P + D * hit.t;                      // ray_transfer, fs:69
-                R = D - n * (2.0f * dot3(n, D));                  // reflect(), fs:86
-                P2 = at + n * .0001f;                             // surface fudge, fs:87
-                const float fresnel = pow5(dot3(D, R) * .5f + .5f);
-                object_specular = spec + (mk(1.0f, 1.0f, 1.0f) - spec) * fresnel;   // f_schlick_vr, fs:479-482
+                const ShadedHit sh = shade_hit(sc, fr, spec, P, D, hit);
+                n = sh.n;
+                R = sh.R;
+                P2 = sh.P2;
+                object_specular = sh.object_specular;
             }
             if (has_diffuse) {                                    // uniform
                 bool lit = true;
                 if (fr.cast_shadows) {                            // uniform
                     Hit shadow{kFar, -1.0f, 0.0f, 0.0f};
-                    pool.template closest<COUNT, SHRAY_SHADOW_ANY_HIT != 0>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
+                    pool.template closest<COUNT, SHRAY_SHADOW_ANY_HIT != 0, TIMED_FORM>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
                                                  xform(fr.object_normal_matrix, light, 0.0f), shadow, rc);
                     lit = shadow.t >= kFar;
                 }

@@ -145,6 +145,24 @@ __device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t n
     hi = p[1];
 }
 
+// range_intersect_box of the node's box against [0, 1e8] (fs:200-217, :272-275): the entry plane is the box's low
+// side when D >= 0, else its high side.  The arithmetic the shader demands of a node visit: 6 selects, 6 subtractions,
+// 6 quotients, 6 min / max (profiles/isa_costs.py counts it in isolation).
+__device__ __forceinline__ void slab_range(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
+{
+    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
+    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
+    r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
+               div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
+    r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
+               div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
+    if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
+        r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
+        r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
+    }
+}
+
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
 // (A predicated form of the bookkeeping below -- every side effect once, under its own condition: 75 instead of
 // 96 vector instructions per visit in the ISA -- was measured in rounds 1 and 2 and is 3-8 % SLOWER on every
@@ -159,19 +177,8 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     if (COUNT && (b & kLeafFlag))
         rc.leaf_visits++;   // the reference fetches (start, count) before the box test, fs:263-267
 
-    // range_intersect_box against [0, 1e8] (fs:200-217): the entry plane is the box's low
-    // side when D >= 0, else its high side
-    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
-    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
-    // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
-    float r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
-                     div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
-    float r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
-                     div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
-    if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
-        r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
-        r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
-    }
+    float r0, r1;
+    slab_range(t, lo, hi, r0, r1);
 
     if (!(r0 >= r1) && (r0 < t.hit.t)) {
         if (b & kLeafFlag) {
@@ -206,34 +213,52 @@ __device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &
     return lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
 }
 
-// triangle_intersect (fs:297-346) of triangle `which` (its three 16-byte words) for a parked lane
+// triangle_intersect (fs:297-346) in its two halves (profiles/isa_costs.py counts each in isolation).
+// First half, fs:307-331: determinant, distance, the early-outs against the determinant's epsilon, the closest hit so
+// far and the leaf's clipped range.  Returns false where the shader returns.
+struct TriangleSetup {
+    V3 M, T, Q;
+    float inv_det, dist;
+};
+__device__ __forceinline__ bool triangle_distance(const LaneTraversal &t, const float4 q0, const float4 q1, const float4 q2,
+                                                  TriangleSetup &s)
+{
+    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
+    s.M = cross3(e1, t.D);
+    const float det = dot3(e0, s.M);
+    if (det > -0.0000001f && det < 0.0000001f)
+        return false;
+    s.inv_det = 1.0f / det;
+    s.T = t.P - v0;
+    s.Q = cross3(s.T, e0);
+    s.dist = -dot3(e1, s.Q) * s.inv_det;
+    return !(s.dist > t.hit.t || s.dist < t.leaf_r0 || s.dist > t.leaf_r1);
+}
+// Second half, fs:333-346: the barycentric tests and the store.
+__device__ __forceinline__ void triangle_barycentrics(LaneTraversal &t, uint32_t which, const TriangleSetup &s)
+{
+    const float u = dot3(s.T, s.M) * s.inv_det;
+    if (u < 0.0f || u > 1.0f)
+        return;
+    const float w = dot3(t.D, s.Q) * s.inv_det;
+    if (w < 0.0f || u + w > 1.0f)
+        return;
+    t.hit.which = (float)which;
+    t.hit.t = s.dist;
+    t.hit.bu = u;
+    t.hit.bv = w;
+}
+
+// triangle_intersect of triangle `which` (its three 16-byte words) for a parked lane
 template <bool COUNT>
 __device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint32_t which, RayCounters &rc,
                                                           const float4 q0, const float4 q1, const float4 q2)
 {
     if (COUNT)
         rc.triangle_tests++;
-    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
-    const V3 M = cross3(e1, t.D);
-    const float det = dot3(e0, M);
-    if (det > -0.0000001f && det < 0.0000001f)
-        return;
-    const float inv_det = 1.0f / det;
-    const V3 T = t.P - v0;
-    const V3 Q = cross3(T, e0);
-    const float dist = -dot3(e1, Q) * inv_det;
-    if (dist > t.hit.t || dist < t.leaf_r0 || dist > t.leaf_r1)
-        return;
-    const float u = dot3(T, M) * inv_det;
-    if (u < 0.0f || u > 1.0f)
-        return;
-    const float w = dot3(t.D, Q) * inv_det;
-    if (w < 0.0f || u + w > 1.0f)
-        return;
-    t.hit.which = (float)which;
-    t.hit.t = dist;
-    t.hit.bu = u;
-    t.hit.bv = w;
+    TriangleSetup s;
+    if (triangle_distance(t, q0, q1, q2, s))
+        triangle_barycentrics(t, which, s);
 }
 
 // The nine floats of a packed triangle, fetched as three 12-byte loads issued back to back and handed on as the

@@ -79,6 +79,17 @@ class Scene:
             out.ctypes.data_as(N.c_float_p) if want_image else None, C.byref(counters)))
         return out, counters.as_dict()
 
+    def render_counters_timed(self, params: N.FrameParams, width: int, height: int, spp: int = 1, frames_per_launch: int = 1,
+                              want_image: bool = True):
+        """Tallies of the instance the timed launches run (shadow rays stop at their first hit, samples in neighbouring
+        lanes): shray_render_counters_timed."""
+        out = np.empty((height, width, 4), dtype=np.float32) if want_image else None
+        counters = N.Counters()
+        N.check(self._lib.shray_render_counters_timed(
+            self._handle, C.byref(params), width, height, spp, frames_per_launch,
+            out.ctypes.data_as(N.c_float_p) if want_image else None, C.byref(counters)))
+        return out, counters.as_dict()
+
     def render_into(self, params: N.FrameParams, width: int, height: int, spp: int, out_ptr: int,
                     stream_ptr: int = 0, tiles: N.TileSet | None = None):
         """Asynchronous render into device memory (`out_ptr`, e.g. tensor.data_ptr()) on a

@@ -20,6 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def step_frames(s, steps, frames):
+    """frames of step s: the last of several steps is one frame short (a frame loop's tail)"""
+    return frames - 1 if (steps > 1 and s == steps - 1 and frames > 1) else frames
+
+
 def run_ranks(pkg, world_file, env, W, H, spp, ranks, frames, mode, shares, rgb, steps, materials):
     """`steps` steps of `frames` frames on `ranks` loopback ranks; returns {(step, frame): [H, W, 4] array}."""
     import torch
@@ -42,15 +47,12 @@ def run_ranks(pkg, world_file, env, W, H, spp, ranks, frames, mode, shares, rgb,
             barrier.wait()
             mine = {}
             for s in range(steps):
-                count = frames if s + 1 < steps or frames == 1 else frames - 1     # the last step is short
-                me.step(params[s][:count], s % 2, streams[s % 2].cuda_stream)
+                me.step(params[s][:step_frames(s, steps, frames)], s % 2, streams[s % 2].cuda_stream)
                 # frames are fetched a step late: the next step is already enqueued on the other stream / buffer set
                 if s > 0:
-                    prev = frames
-                    for f, t in me.frames((s - 1) % 2, prev, streams[(s - 1) % 2].cuda_stream).items():
+                    for f, t in me.frames((s - 1) % 2, step_frames(s - 1, steps, frames), streams[(s - 1) % 2].cuda_stream).items():
                         mine[(s - 1, f)] = t
-            last = frames if steps == 1 or frames == 1 else frames - 1
-            for f, t in me.frames((steps - 1) % 2, last, streams[(steps - 1) % 2].cuda_stream).items():
+            for f, t in me.frames((steps - 1) % 2, step_frames(steps - 1, steps, frames), streams[(steps - 1) % 2].cuda_stream).items():
                 mine[(steps - 1, f)] = t
             torch.cuda.synchronize()
             with lock:
@@ -89,8 +91,7 @@ def test_loopback_ranks_assemble_the_full_frames(pkg, gpu, ranks, frames, mode, 
     scene = pkg.Scene(pkg.World(path).flatten(), env, device=0)
     expected = set()
     for s in range(steps):
-        count = frames if s + 1 < steps or frames == 1 else frames - 1
-        for f in range(count):
+        for f in range(step_frames(s, steps, frames)):
             expected.add((s, f))
             want = scene.render(params[s][f], W, H, spp)
             assert np.array_equal(got[(s, f)].view(np.uint32), want.view(np.uint32)), (ranks, frames, mode, s, f)

@@ -169,6 +169,36 @@ def test_nan_candidates_in_a_dealt_leaf(pkg, gpu, oracle_mod):
                 scene.close()
 
 
+@pytest.mark.parametrize("spp", [1, 4])
+def test_counters_of_the_timed_instances(pkg, gpu, oracle_mod, bunny, env_sky, spp):
+    """shray_render_counters_timed: the tallies of the instance the timed launches run (one-wave workgroups, sample
+    lanes, shadow rays that stop at their first hit).  For a metal there are no shadow rays: every tally equals the
+    oracle's.  For the diffuse material the shadow rays do less work than the reference's full traversals -- fewer node
+    visits and triangle tests, the same traversals, hits, lookups -- and the image is the same bit for bit."""
+    world, desc, scene = bunny
+    scene.set_kernel(0)
+    W, H = 192, 112
+    for material in (0, 6):
+        params = world.frame_params(W, H, material=material)
+        want, cpu = oracle_mod.render(desc, env_sky, params, W, H, spp)
+        for frames_per_launch in (1, 2):           # the dealt and the plain leaf stage (capi.hip: leaf_stage_policy)
+            got, timed = scene.render_counters_timed(params, W, H, spp, frames_per_launch)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (material, spp, frames_per_launch)
+            if material == 0:
+                assert timed == cpu, (timed, cpu)
+            else:
+                same = ("shaded_hits", "env_lookups", "traversals", "bad_hits", "samples")
+                assert all(timed[k] == cpu[k] for k in same), (timed, cpu)
+                assert timed["node_visits"] < cpu["node_visits"] and timed["triangle_tests"] < cpu["triangle_tests"]
+                assert timed["leaf_visits"] <= cpu["leaf_visits"]
+                assert timed["node_visits"] > cpu["node_visits"] // 2      # the primary rays' walks are all there
+    # kernels without a timed form of their own report their ordinary counters
+    params = world.frame_params(W, H, material=6)
+    scene.set_kernel(1)
+    assert scene.render_counters_timed(params, W, H, 1)[1] == scene.render_counters(params, W, H, 1)[1]
+    scene.set_kernel(0)
+
+
 def test_empty_world_renders_environment(pkg, gpu, oracle_mod, tmp_path):
     path = tmp_path / "empty.trisrc"
     path.write_text("")

@@ -3,22 +3,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Workload (BASELINE.json configs[1]): bunny-class mesh (69,168 triangles, written as
-trisrc text and loaded through the real parser + BVH builder), seeded HDR sky environment,
-1920x1080, 1 spp, default gold material, 3 bounces.  A "step" is one frame: every rank
-renders its interleaved tiles with the HIP kernel and (N > 1) the packed tile buffers are
-gathered to rank 0 over RCCL and de-interleaved.  Scene and environment are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line.
+Workload (BASELINE.json configs[1]): bunny-class mesh (69,168 triangles, written as trisrc text and loaded
+through the real parser + BVH builder), seeded HDR sky environment, 1920x1080, 1 spp, default gold material,
+3 bounces.  A "step" is one frame of a trackball orbit (the frame loop of ray.cpp:1096-1131 with a mouse drag,
+ray.cpp:879-918: ORBIT distinct views, replayed): scene and environment are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
 
-Successive frames are independent.  N = 1: the frame loop hands the C ABI two frames per launch and
-alternates launches over four HIP streams (profiles/r02/leaf_stage_ab.txt section 10).  N > 1: a
-launch carries N consecutive frames (the rank's tiles of each; shray_render_batch_device), one
-gather moves all N, and two such launches alternate on two streams -- a rank's share of ONE
-frame is latency-bound, see DESIGN.md section 6.  Exactly K frames are rendered in the timed
-region either way (the last launch is shorter when N does not divide K).
+N = 1: the frame loop hands the C ABI two frames per launch (shray_render_batch_device) and alternates launches
+over four HIP streams.  N > 1 (one process per GPU): every rank drives libshray_dist.so (shray_dist_step): a step of
+the library carries N consecutive frames -- the rank's interleaved tiles of each in one launch, RGB tile buffers
+exchanged with grouped ncclSend / ncclRecv over xGMI, frame f of the step de-interleaved on rank f % N (rotating
+roots; --root-mode root0 gathers every frame on rank 0) -- and two such steps alternate on two streams and two buffer
+sets.  Exactly K frames are rendered in the timed region either way (the last launch is shorter when the frames per
+launch do not divide K).  torch.distributed (gloo) is the control plane only: rendezvous, barrier, max-over-ranks.
 
 For N > 1 launch as
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
@@ -29,10 +29,8 @@ import os
 import sys
 import time
 
-# Two frames are kept in flight on two HIP streams; they only overlap when the streams land on
-# different hardware queues.  With the runtime's default queue count the side stream was seen to
-# alias the queue RCCL's stream uses (no overlap at all); an explicit count avoids that.  Must be
-# set before the HIP runtime initialises.
+# Independent launches are kept in flight on several HIP streams; they only overlap when the streams land on
+# different hardware queues.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,14 +38,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WIDTH, HEIGHT, SPP = 1920, 1080, 1
+ORBIT = 20                 # distinct views of the orbit; frame k of a run is view k % ORBIT
+ORBIT_DRAG = (0.025, 0.010)  # the mouse drag per frame, in window fractions (trackball_motion, ray.cpp:91-98)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # VALU issue peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-instructions / s
-PMC_FILE = os.path.join("profiles", "r02", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
+PMC_FILE = os.path.join("profiles", "r03", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
+ISA_COSTS = os.path.join("profiles", "r03", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
+WARM_SECONDS = 0.15        # back-to-back frames before the first trial, beyond the W warm-up steps: the GPU's clock ramps
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def orbit_params(pkg, world, width, height, material=0):
+    """ORBIT frame blocks: the start-up view dragged ORBIT_DRAG further every frame."""
+    view = world.default_view()
+    view.which_material = material
+    out = []
+    for _ in range(ORBIT):
+        pkg.host.trackball_motion(view.object_rotation, *ORBIT_DRAG)
+        out.append(world.frame_params(width, height, view))
+    return out
 
 
 def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
@@ -66,8 +79,16 @@ def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
             break
     dt = elapsed / reps
     return {"value": round(WIDTH * HEIGHT * SPP / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"the full {WIDTH}x{HEIGHT} frame of the same workload, {reps} repetitions in {elapsed:.1f} s, "
-                      f"CPU oracle with {threads} threads"}
+            "sample": f"the full {WIDTH}x{HEIGHT} frame of the same workload (first view of the orbit), {reps} repetitions in "
+                      f"{elapsed:.1f} s, CPU oracle with {threads} threads"}
+
+
+def algorithmic_ops(counters, costs):
+    """Lane-instructions of the shader's own arithmetic for the work the counters describe (profiles/isa_costs.py)."""
+    c, k = counters, costs
+    return (k["c_node"] * c["node_visits"] + k["c_tri_distance"] * c["triangle_tests"]
+            + (k["c_tri_barycentric"] + k["c_shade"]) * c["shaded_hits"] + k["c_setup"] * c["traversals"]
+            + k["c_env"] * c["env_lookups"] + k["c_pixel"] * c["samples"])
 
 
 def main():
@@ -83,13 +104,18 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="frame width (default: the headline configuration)")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel; --width 3840 --height 2160 --spp 16 is BASELINE configs[4]")
+    ap.add_argument("--material", type=int, default=0, help="0 = gold (the headline), 6 = glazed plaster with diffuse white (configs[2])")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent launches alternate over this many HIP streams (1 = strictly one at a time; "
                          "default: 4 for N = 1, 2 for N > 1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="consecutive frames per launch (shray_render_batch_device); N > 1: also per gather.  Default: 2 for "
-                         "N = 1, the number of GPUs for N > 1 (a launch then carries one frame's worth of pixels per GPU)")
-    ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: gather RGBA instead of RGB (alpha is the constant 1)")
+                    help="consecutive frames per launch (shray_render_batch_device / shray_dist_step).  Default: 2 for "
+                         "N = 1, the number of GPUs for N > 1 (a step then carries one frame's worth of pixels per GPU)")
+    ap.add_argument("--root-mode", choices=["rotate", "root0"], default="rotate",
+                    help="N > 1: rotate = frame f of a step is assembled on rank f % N (all-to-all over every xGMI link); "
+                         "root0 = every frame on rank 0 (gather)")
+    ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: exchange RGBA instead of RGB (alpha is the constant 1)")
+    ap.add_argument("--same-view", action="store_true", help="every frame renders the first view of the orbit (round 2's loop)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
 
@@ -102,25 +128,21 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-    # SHRAY_FORCE_DIST=1 rehearses the multi-GPU code path (process group, barrier, gather) with one rank
+    if args.gpus != world_size and world_size == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    # SHRAY_FORCE_DIST=1 rehearses the multi-GPU code path (process group, barrier, shray_dist_step) with one rank
     distributed = world_size > 1 or os.environ.get("SHRAY_FORCE_DIST") == "1"
-    # Rehearsal on a single-GPU box: SHRAY_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
-    # SHRAY_BENCH_BACKEND=gloo swaps RCCL (which refuses two ranks on one GPU) for gloo, staging the
-    # gather through host memory.  Only the control flow is rehearsed that way, never a reported number.
+    # Rehearsal on a single-GPU box: SHRAY_BENCH_ONE_GPU=1 puts every rank on cuda:0 and SHRAY_BENCH_TRANSPORT=gloo swaps
+    # RCCL (which refuses two ranks on one GPU) for the library's CALLBACK transport over gloo, staging the tile buffers
+    # through host memory.  Only the control flow is rehearsed that way, never a reported number.
     one_gpu = os.environ.get("SHRAY_BENCH_ONE_GPU") == "1"
-    backend = os.environ.get("SHRAY_BENCH_BACKEND", "nccl")
+    transport_name = os.environ.get("SHRAY_BENCH_TRANSPORT", "rccl")
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")     # control plane only; the pixels travel over RCCL inside libshray_dist.so
 
     pkg = load_package()
     # rank 0 generates the scene file once; the others wait for it
@@ -132,39 +154,46 @@ def main():
     world = pkg.World(path)
     desc = world.flatten()
     env = pkg.scenes.environment_hdr_sky(2048)
-    params = world.frame_params(WIDTH, HEIGHT, material=0)
+    orbit = orbit_params(pkg, world, WIDTH, HEIGHT, args.material)
+    if args.same_view:
+        orbit = [orbit[0]] * ORBIT
     scene = pkg.Scene(desc, env, device=local_rank)
     scene.set_kernel(args.kernel)
-    stream = torch.cuda.current_stream().cuda_stream
 
     from shader_ray_amd import multigpu
 
     tile = multigpu.DEFAULT_TILE
-
-    # Successive frames are independent.  With one frame at a time the last ~35 % of a 1 spp 1080p
-    # frame is a tail of a few heavy waves on an otherwise idle GPU; alternating
-    # frames over two HIP streams (double buffering, as any frame loop does) lets frame k+1's bulk
-    # fill frame k's tail -- and, with several GPUs, lets the gather of frame k overlap the render
-    # of frame k+1.  Every frame is still rendered completely into its own buffer.
     lanes = max(1, args.frames_in_flight or (2 if distributed else 4))
-    # N > 1: a rank's share of one 1080p frame is latency-bound (its long-running waves take ~0.5 ms
-    # wherever they land), so a launch carries `batch` consecutive frames (shray_render_batch_device) and
-    # one gather moves them all: fewer, larger collectives, and the GPU stays full.
-    # N = 1: the frame loop hands the C ABI two frames per launch (shray_render_batch_device, the throughput form of
-    # the frame loop, ray.cpp:1096-1131); --frames-per-launch 1 --frames-in-flight 1 is strictly one frame at a time
+    if distributed:
+        lanes = min(lanes, 4)      # buffer sets of a shray_dist object
     batch = max(1, min(64, args.frames_per_launch or (world_size if distributed else 2)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
-    frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
-    splits = [multigpu.DistributedFrame(WIDTH, HEIGHT, tile, tile, device=device, always_gather=True,
-                                        stage_through_host=(backend != "nccl"), frames=batch,
-                                        rgb_wire=not args.rgba_wire) for _ in range(lanes)] if distributed else None
+    frame_outs = None
+    me = None
+    if distributed:
+        root_mode = multigpu.ROTATE if args.root_mode == "rotate" else multigpu.ROOT0
+        if transport_name == "gloo":
+            cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.CALLBACK, None, tile, tile,
+                                       not args.rgba_wire, buffer_sets=lanes)
+            me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
+        else:
+            ids = [multigpu.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.RCCL, None, tile, tile,
+                                       not args.rgba_wire, buffer_sets=lanes)
+            me = multigpu.Rank(scene, cfg, ids[0])      # collective: ncclCommInitRank
+    else:
+        frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     trials = max(1, args.trials)
-    starts, stops, launch_frames = [], [], []
+    starts, stops = [], []
     EVENT_STRIDE = max(1, int(os.environ.get("SHRAY_BENCH_EVENT_STRIDE", "4")))
     torch.cuda.synchronize()
 
-    def step(j, count, timed=None):
-        """launch j of the single-GPU path: `count` consecutive frames; timed: HIP events bracket the launch"""
+    def views(first, count):
+        return [orbit[(first + k) % ORBIT] for k in range(count)]
+
+    def step(j, first, count, timed=None):
+        """launch j: frames first .. first + count - 1 of the orbit; timed: HIP events bracket the launch"""
         lane = j % lanes
         st = streams[lane]
         # HIP events bracket every EVENT_STRIDE-th launch of the timed region (an event is a barrier packet on its stream:
@@ -174,47 +203,25 @@ def main():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             starts.append(a)
             stops.append(b)
-            launch_frames.append(count)
             a.record(st)
-        if count == 1:
-            scene.render_into(params, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
+        if distributed:
+            me.step(views(first, count), lane, st.cuda_stream)
+        elif count == 1:
+            scene.render_into(orbit[first % ORBIT], WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
         else:
-            scene.render_batch_into([params] * count, WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), HEIGHT * WIDTH * 16,
+            scene.render_batch_into(views(first, count), WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), HEIGHT * WIDTH * 16,
                                     st.cuda_stream, None)
         if timed is not None:
             b.record(st)
-        return frame_outs[lane]
-
-    def launch(j, count):
-        """`count` frames: this rank's tiles in one launch, one gather to rank 0, one de-interleave"""
-        lane = j % lanes
-        st = streams[lane]
-        split = splits[lane]
-
-        def render_tiles(tile_set, out):
-            scene.render_batch_into([params] * count, WIDTH, HEIGHT, SPP, out.data_ptr(), split.frame_stride_bytes,
-                                    st.cuda_stream, tile_set)
-        with torch.cuda.stream(st):
-            return split.render(render_tiles, count)
 
     def run(frames, timed=None):
-        """exactly `frames` frames; returns what the last launch produced"""
-        last = None
-        if not distributed:
-            done = j = 0
-            while done < frames:
-                count = min(batch, frames - done)
-                last = step(j, count, timed)
-                done += count
-                j += 1
-            return last
+        """exactly `frames` frames"""
         done = j = 0
         while done < frames:
             count = min(batch, frames - done)
-            last = launch(j, count)
+            step(j, done, count, timed)
             done += count
             j += 1
-        return last
 
     def fence():
         if distributed:
@@ -223,150 +230,215 @@ def main():
 
     run(args.warmup)
     fence()
+    # the clock of an idle GPU ramps for tens of milliseconds under load (round 2: ten 5 ms trials rose monotonically);
+    # keep rendering, untimed, until WARM_SECONDS have passed
+    t0 = time.perf_counter()
+    warm_frames = 0
+    while time.perf_counter() - t0 < WARM_SECONDS:
+        run(ORBIT)                 # whole periods of the orbit: a profile of this command averages over every view alike
+        warm_frames += ORBIT
+        fence()
+    warm_ms = (time.perf_counter() - t0) * 1e3
 
     # `trials` repetitions of the timed region; each one is EXACTLY K steps between two fences (barrier +
     # synchronize), its time the MAX over ranks.  The median trial is what the JSON line reports, so that a
-    # short K (the driver's --steps 20 is 7 ms of GPU time) is not a single noisy sample.
+    # short K (the driver's --steps 20 is 5 ms of GPU time) is not a single noisy sample.
     trial_s = []
     for trial in range(trials):
+        fence()
         t0 = time.perf_counter()
         run(args.steps, timed=trial)
         fence()
         dt = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         trial_s.append(dt)
     elapsed = sorted(trial_s)[len(trial_s) // 2]
 
     if distributed and os.environ.get("SHRAY_BENCH_CHECK") == "1":
-        # rehearsal aid (every rank takes part in the extra launch): every assembled frame must
-        # equal a single-GPU render of the whole frame
-        last = run(batch)
+        # rehearsal aid (every rank takes part in the extra step): every assembled frame must equal a single-GPU
+        # render of the whole frame
+        me.step(views(0, batch), 0, streams[0].cuda_stream)
+        mine = me.frames(0, batch, streams[0].cuda_stream)
         torch.cuda.synchronize()
-        if rank == 0:
-            whole = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
-            scene.render_into(params, WIDTH, HEIGHT, SPP, whole.data_ptr(), torch.cuda.current_stream().cuda_stream, None)
+        whole = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
+        same = True
+        for f, got in mine.items():
+            scene.render_into(orbit[f % ORBIT], WIDTH, HEIGHT, SPP, whole.data_ptr(), torch.cuda.current_stream().cuda_stream, None)
             torch.cuda.synchronize()
-            last = last if last.dim() == 4 else last.unsqueeze(0)
-            same = all(bool(torch.equal(last[f].reshape(-1), whole)) for f in range(last.shape[0]))
-            log(f"all {last.shape[0]} assembled frame(s) equal the single-GPU frame:", same)
+            same = same and bool(torch.equal(got.reshape(-1), whole))
+        everyone = [None] * world_size
+        dist.all_gather_object(everyone, (sorted(mine), same))
+        if rank == 0:
+            frames_seen = sorted(f for fs, _ in everyone for f in fs)
+            log(f"assembled frames {frames_seen} of a step of {batch}; all equal the single-GPU frames:", all(ok for _, ok in everyone))
 
     result = None
+    frames_per_s = args.steps / elapsed
     if rank == 0:
         rays = WIDTH * HEIGHT * SPP * args.steps
+        headline = (WIDTH, HEIGHT, SPP, args.material) == (1920, 1080, 1, 0)
         result = {
-            "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling" if (WIDTH, HEIGHT, SPP) == (1920, 1080, 1)
+            "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling" if headline
             else f"Mrays/s at {WIDTH}x{HEIGHT} {SPP}spp (bunny.trisrc)",
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "trials": trials, "trial_ms": [round(t * 1e3, 4) for t in trial_s],
-            "timing": f"median of {trials} trials of exactly {args.steps} steps, each between barrier + synchronize fences",
+            "timing": f"median of {trials} trials of exactly {args.steps} steps, each between barrier + synchronize fences; "
+                      f"after the {args.warmup} warm-up steps the loop ran untimed for {warm_ms:.0f} ms ({warm_frames} frames) so that the "
+                      "clock has ramped before the first trial",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
-                                   f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, gold, 3 bounces"
-                                   + (" (BASELINE configs[1])" if (WIDTH, HEIGHT, SPP) == (1920, 1080, 1) else ""),
+                                   f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, "
+                                   + ("gold" if args.material == 0 else f"material {args.material}") + ", 3 bounces"
+                                   + (" (BASELINE configs[1])" if headline else "")
+                                   + (f"; the frames are a trackball orbit of {ORBIT} views, replayed" if not args.same_view else "; one view"),
                        "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "pool"}[args.kernel],
-                       "parallelism": f"tiles{tile}x{tile}-interleaved-x{world_size}" if distributed else "single-gpu",
+                       "parallelism": (f"tiles{tile}x{tile}-interleaved-x{world_size}, libshray_dist ({transport_name}), "
+                                       f"{'rotating roots (all-to-all)' if args.root_mode == 'rotate' else 'gather to rank 0'}")
+                       if distributed else "single-gpu",
                        "frames_in_flight": lanes * batch, "frames_per_launch": batch, "streams": lanes,
                        "wire": ("rgb32f" if not args.rgba_wire else "rgba32f") if distributed else None},
         }
-    if distributed and rank == 0:
-        # all ranks together execute exactly the fetches of the whole frame: per-GPU algorithmic rate
-        _, counters = scene.render_counters(params, WIDTH, HEIGHT, SPP, want_image=False)
-        algo_bytes = pkg.tracer.algorithmic_bytes(counters, WIDTH * HEIGHT, normals_fp16=True)
-        per_gpu = algo_bytes * args.steps / elapsed / 1e9 / world_size
-        result["roofline"] = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Gwaveinst/s", "frac": None,
-                              "traffic": None, "traffic_source": "not collected for N > 1 (see the N = 1 line)",
-                              "algorithmic_cacheless": {"bytes_per_frame": algo_bytes, "gbs_per_gpu": round(per_gpu, 2),
-                                                        "note": "cache-less count of the reference's fetches / wall time / n_gpus "
-                                                                "(gather and de-interleave included in the time); not a bound"}}
-        result["counters"] = counters
-    if not distributed:
-        # per-launch kernel time: HIP events recorded around every EVENT_STRIDE-th launch of every trial, on the stream that
-        # launch went to.  With frames_in_flight > 1 two launches share the GPU, so each lasts longer than it
-        # would alone while the pair finishes sooner: rates below use WALL time, not per-launch time.
-        kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-        avg_ms = sum(kernel_ms) / len(kernel_ms)   # per LAUNCH (a launch carries `batch` frames)
-        _, counters = scene.render_counters(params, WIDTH, HEIGHT, SPP, want_image=False)
-        algo_bytes = pkg.tracer.algorithmic_bytes(counters, WIDTH * HEIGHT, normals_fp16=True)
-        frames_per_s = args.steps / elapsed
-        # hardware counters of the dominant kernel come from a committed rocprofv3 --pmc run of THIS command
-        # (they cannot be read from inside the process); used only if they were taken on this workload
-        pmc, pmc_note = None, "no counter file"
+
+    # work counters of the orbit: the counting kernels' (the reference's traversals, equal to the CPU oracle's) and
+    # the timed instances' own (shadow rays stop at their first hit; equal for the gold headline)
+    if rank == 0:
+        sums, timed_sums = {}, {}
+        for view in (orbit[:1] if args.same_view else orbit):
+            _, c = scene.render_counters(view, WIDTH, HEIGHT, SPP, want_image=False)
+            _, ct = scene.render_counters_timed(view, WIDTH, HEIGHT, SPP, batch if not distributed else 1, want_image=False)
+            for k in c:
+                sums[k] = sums.get(k, 0) + c[k]
+                timed_sums[k] = timed_sums.get(k, 0) + ct[k]
+        nviews = 1 if args.same_view else ORBIT
+        counters = {k: v / nviews for k, v in sums.items()}
+        counters_timed = {k: v / nviews for k, v in timed_sums.items()}
+        result["counters"] = {"per_frame_mean_over_the_orbit": counters, "of": "the counting kernels = the reference's traversal (every shadow "
+                              "ray walked to its end), equal to the CPU oracle's"}
+        result["counters_timed"] = {"per_frame_mean_over_the_orbit": counters_timed,
+                                    "of": "the instance the timed launches run (shray_render_counters_timed)"}
+        result["traversals_per_s"] = round(counters_timed["traversals"] * frames_per_s, 1)
+        algo_bytes = pkg.tracer.algorithmic_bytes({k: int(v) for k, v in counters.items()}, WIDTH * HEIGHT, normals_fp16=True)
+        costs, costs_note = None, ISA_COSTS
         try:
-            sys.path.insert(0, os.path.join(ROOT, "profiles"))
-            from buildhash import kernel_source_hash
-            cand = json.load(open(os.path.join(ROOT, PMC_FILE)))
-            wl = cand["workload"]
-            if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"], wl.get("frames_per_launch", 1)) == \
-                    (WIDTH, HEIGHT, SPP, args.kernel, batch) and cand["valu_insts_per_launch"]:
-                pmc = cand
-                pmc_note = PMC_FILE + (" (same kernel sources as this build)" if cand["build_hash"] == kernel_source_hash()
-                                       else " (STALE: measured on different kernel sources than this build)")
-            else:
-                pmc_note = PMC_FILE + " is for another workload"
+            costs = json.load(open(os.path.join(ROOT, ISA_COSTS)))
         except Exception as exc:   # noqa: BLE001
-            pmc_note = f"{PMC_FILE} unreadable: {exc}"
+            costs_note = f"{ISA_COSTS} unreadable: {exc}"
         roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Gwaveinst/s", "frac": None,
-                "lane_util": None, "traffic": None, "traffic_source": pmc_note, "hbm_frac": None,
-                "counter_source": pmc_note,
+                "traffic": None,
                 "why": "the scene + environment working set (32 MB) is cache-resident: the kernel is bound by VALU issue, "
-                       "not by HBM (DESIGN.md section 4.4); HBM use is reported as hbm_frac"}
-        if pmc:
-            fpl = pmc["workload"].get("frames_per_launch", 1)   # the profiled launches carried this many frames each
-            ginst = pmc["valu_insts_per_launch"] / fpl * frames_per_s / 1e9
-            roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 5),
-                         "lane_util": round(pmc["lane_util"], 4) if pmc.get("lane_util") else None,
-                         "useful_frac": round(ginst / VALU_PEAK_GINST * pmc["lane_util"], 5) if pmc.get("lane_util") else None,
-                         "valu_insts_per_frame": pmc["valu_insts_per_launch"] / fpl,
-                         "profiled_kernel_us": pmc.get("kernel_trace_avg_us")})
-            if pmc.get("hbm_bytes_per_launch"):
-                hbm_gbs = pmc["hbm_bytes_per_launch"] / fpl * frames_per_s / 1e9
-                roof.update({"traffic": pmc["hbm_bytes_per_launch"], "traffic_frames": fpl, "hbm_gbs": round(hbm_gbs, 2),
-                             "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 5)})
+                       "not by HBM (DESIGN.md section 4); HBM use is reported as hbm_frac"}
+        if costs:
+            # wave-instructions a frame would take if every lane of every instruction did arithmetic the shader asks for
+            ops = algorithmic_ops(counters_timed, costs) / 64.0
+            gops = ops * frames_per_s / 1e9 / (world_size if distributed else 1)
+            roof["algorithmic_ops"] = {
+                "wave_insts_per_frame": round(ops, 1), "gwaveinst_per_s_per_gpu": round(gops, 2),
+                "costs": {k: v for k, v in costs.items() if k.startswith("c_")}, "costs_source": costs_note,
+                "formula": "(c_node Nv + c_tri_distance Tt + (c_tri_barycentric + c_shade) H + c_setup Tr + c_env E + c_pixel S) / 64 "
+                           "from counters_timed; tests that reach the barycentric part are counted as H (a lower bound)"}
+            roof["necessary_frac"] = round(gops / VALU_PEAK_GINST, 5)
+        if not distributed:
+            # per-launch kernel time: HIP events recorded around every EVENT_STRIDE-th launch of every trial, on the stream that
+            # launch went to.  With frames_in_flight > 1 several launches share the GPU, so each lasts longer than it
+            # would alone while together they finish sooner: rates below use WALL time, not per-launch time.
+            kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+            avg_ms = sum(kernel_ms) / len(kernel_ms)   # per LAUNCH (a launch carries `batch` frames)
+            # hardware counters of the dominant kernel come from a committed rocprofv3 --pmc run of THIS command
+            # (they cannot be read from inside the process); used only if they were taken on this workload
+            pmc, pmc_note = None, "no counter file"
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                from buildhash import kernel_source_hash
+                cand = json.load(open(os.path.join(ROOT, PMC_FILE)))
+                wl = cand["workload"]
+                if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"], wl.get("frames_per_launch", 1), wl.get("orbit", 1)) == \\
+                        (WIDTH, HEIGHT, SPP, args.kernel, batch, 1 if args.same_view else ORBIT) and cand["valu_insts_per_launch"] \\
+                        and args.material == 0:
+                    pmc = cand
+                    pmc_note = PMC_FILE + (" (same kernel sources as this build)" if cand["build_hash"] == kernel_source_hash()
+                                           else " (STALE: measured on different kernel sources than this build)")
+                else:
+                    pmc_note = PMC_FILE + " is for another workload"
+            except Exception as exc:   # noqa: BLE001
+                pmc_note = f"{PMC_FILE} unreadable: {exc}"
+            roof.update({"traffic_source": pmc_note, "counter_source": pmc_note, "lane_util": None, "hbm_frac": None})
+            if pmc:
+                fpl = pmc["workload"].get("frames_per_launch", 1)   # the profiled launches carried this many frames each
+                ginst = pmc["valu_insts_per_launch"] / fpl * frames_per_s / 1e9
+                roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 5),
+                             "lane_util": round(pmc["lane_util"], 4) if pmc.get("lane_util") else None,
+                             "useful_frac": round(ginst / VALU_PEAK_GINST * pmc["lane_util"], 5) if pmc.get("lane_util") else None,
+                             "valu_insts_per_frame": pmc["valu_insts_per_launch"] / fpl,
+                             "profiled_kernel_us": pmc.get("kernel_trace_avg_us")})
+                if costs:
+                    roof["necessary_of_issued"] = round(roof["algorithmic_ops"]["wave_insts_per_frame"] / (pmc["valu_insts_per_launch"] / fpl), 4)
+                if pmc.get("hbm_bytes_per_launch"):
+                    hbm_gbs = pmc["hbm_bytes_per_launch"] / fpl * frames_per_s / 1e9
+                    roof.update({"traffic": pmc["hbm_bytes_per_launch"], "traffic_frames": fpl, "hbm_gbs": round(hbm_gbs, 2),
+                                 "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 5)})
+            roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
+                         "concurrent_launches": lanes, "frames_per_launch": batch,
+                         "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed (every {EVENT_STRIDE}th)"})
+        else:
+            roof["traffic_source"] = "not collected for N > 1 (see the N = 1 line)"
         algo_gbs = algo_bytes * frames_per_s / 1e9
         roof["algorithmic_cacheless"] = {
             "bytes_per_frame": algo_bytes, "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
             "gbs": round(algo_gbs, 2),
-            "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x frames / wall time; these bytes are served by "
-                    "L1/L2, not by HBM: not a bound (it exceeds the 8000 GB/s HBM peak), no fraction is formed from it"}
-        roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
-                     "concurrent_launches": lanes, "frames_per_launch": batch,
-                     "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed (every {EVENT_STRIDE}th)"})
+            "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x frames / wall time (all GPUs together); these bytes are "
+                    "served by L1/L2, not by HBM: not a bound (it exceeds the 8000 GB/s HBM peak), no fraction is formed from it"}
         result["roofline"] = roof
-        result["counters"] = counters
+
+    if not distributed:
+        # one frame at a time, in the same run: the latency form of the loop (no batch, no second stream)
+        lat = []
+        solo = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
+        for k in range(5 + 2 * ORBIT):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            scene.render_into(orbit[k % ORBIT], WIDTH, HEIGHT, SPP, solo.data_ptr(), streams[0].cuda_stream, None)
+            torch.cuda.synchronize()
+            if k >= 5:
+                lat.append(time.perf_counter() - t0)
+        lat_ms = sum(lat) / len(lat) * 1e3
+        result["latency"] = {"ms": round(lat_ms, 5), "mrays": round(WIDTH * HEIGHT * SPP / lat_ms / 1e3, 2),
+                             "what": f"one frame per launch, one launch at a time, host-synchronised: mean of {len(lat)} frames of the orbit"}
         # the C ABI's host-buffer forms, PCIe-inclusive, for the record (never `value`): the blocking call into
         # pageable memory (the runtime's staged copy, into a buffer the loop reuses) and the stream form into pinned memory, double-buffered
         from shader_ray_amd.tracer import PinnedFrame
         import numpy as np
         host_frame = np.empty((HEIGHT, WIDTH, 4), dtype=np.float32)   # a frame loop's own (pageable) buffer, reused
-        scene.render(params, WIDTH, HEIGHT, SPP, out=host_frame)      # first touch of its pages
+        scene.render(orbit[0], WIDTH, HEIGHT, SPP, out=host_frame)    # first touch of its pages
         t0 = time.perf_counter()
-        for _ in range(10):
-            scene.render(params, WIDTH, HEIGHT, SPP, out=host_frame)
+        for k in range(10):
+            scene.render(orbit[k % ORBIT], WIDTH, HEIGHT, SPP, out=host_frame)
         result["host_readback_mrays"] = round(WIDTH * HEIGHT * SPP * 10 / (time.perf_counter() - t0) / 1e6, 2)
         pinned = [PinnedFrame(WIDTH, HEIGHT) for _ in range(2)]
-        scene2 = pkg.Scene(desc, env, device=local_rank)   # one in-flight readback per scene: two scenes double-buffer
-        pair = [scene, scene2]
+        scene2 = pkg.Scene(desc, env, device=local_rank)   # one in-flight readback per scene: two scenes double-buffer,
+        pair = [scene, scene2]                             # each on its own stream (calls on one scene stay ordered)
+        two = [torch.cuda.Stream(device=device) for _ in range(2)]
         for k in range(4):
-            pair[k % 2].render_to_pinned(params, WIDTH, HEIGHT, SPP, pinned[k % 2], streams[k % lanes].cuda_stream, wait=False)
+            pair[k % 2].render_to_pinned(orbit[k % ORBIT], WIDTH, HEIGHT, SPP, pinned[k % 2], two[k % 2].cuda_stream, wait=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(20):
-            pair[k % 2].render_to_pinned(params, WIDTH, HEIGHT, SPP, pinned[k % 2], streams[k % lanes].cuda_stream, wait=False)
+            pair[k % 2].render_to_pinned(orbit[k % ORBIT], WIDTH, HEIGHT, SPP, pinned[k % 2], two[k % 2].cuda_stream, wait=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         result["host_readback_pinned_mrays"] = round(WIDTH * HEIGHT * SPP * 20 / dt / 1e6, 2)
         result["host_readback_pinned_gbs"] = round(WIDTH * HEIGHT * 16 * 20 / dt / 1e9, 2)
         scene2.close()
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(pkg, desc, env, params)
+            result["cpu_baseline"] = cpu_baseline(pkg, desc, env, orbit[0])
     if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
+        me.close()
         dist.destroy_process_group()
 
 

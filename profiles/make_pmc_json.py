@@ -34,7 +34,8 @@ fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 out = {
     "kernel": want,
     "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_per_launch": frames_per_launch,
-                 "streams": int(sys.argv[5]) if len(sys.argv) > 5 else 4},
+                 "streams": int(sys.argv[5]) if len(sys.argv) > 5 else 4,
+                 "orbit": int(os.environ.get("SHRAY_PMC_ORBIT", "20"))},   # distinct views the frames cycle through (bench.py: ORBIT)
     "build_hash": kernel_source_hash(),
     "kernel_trace_avg_us": avg_us, "kernel_trace_calls": calls,
     "counters_per_launch": vals,

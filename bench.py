@@ -355,8 +355,8 @@ def main():
                 from buildhash import kernel_source_hash
                 cand = json.load(open(os.path.join(ROOT, PMC_FILE)))
                 wl = cand["workload"]
-                if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"], wl.get("frames_per_launch", 1), wl.get("orbit", 1)) == \\
-                        (WIDTH, HEIGHT, SPP, args.kernel, batch, 1 if args.same_view else ORBIT) and cand["valu_insts_per_launch"] \\
+                if (wl["width"], wl["height"], wl["spp"], wl["kernel_id"], wl.get("frames_per_launch", 1), wl.get("orbit", 1)) == \
+                        (WIDTH, HEIGHT, SPP, args.kernel, batch, 1 if args.same_view else ORBIT) and cand["valu_insts_per_launch"] \
                         and args.material == 0:
                     pmc = cand
                     pmc_note = PMC_FILE + (" (same kernel sources as this build)" if cand["build_hash"] == kernel_source_hash()

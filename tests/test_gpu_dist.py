@@ -122,9 +122,9 @@ def test_rccl_transport_with_one_rank(pkg, gpu):
     W, H = 200, 136
     world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
     scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(128), device=0)
-    uid = multigpu.unique_id()
-    assert len(uid) == 128 and any(uid)
     for mode in (multigpu.ROOT0, multigpu.ROTATE):
+        uid = multigpu.unique_id()          # one id per communicator
+        assert len(uid) == 128 and any(uid)
         cfg = multigpu.make_config(0, 1, W, H, 1, 3, mode, multigpu.RCCL)
         me = multigpu.Rank(scene, cfg, uid)
         params = [world.frame_params(W, H, material=m) for m in (0, 6, 2)]
@@ -137,8 +137,8 @@ def test_rccl_transport_with_one_rank(pkg, gpu):
         me.close()
     N = pkg._native
     with pytest.raises(N.ShrayError):
-        multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 65), uid)          # more frames than SHRAY_MAX_BATCH
-    me = multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 2), uid)
+        multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 65), uid)          # more frames than SHRAY_MAX_BATCH (refused before RCCL)
+    me = multigpu.Rank(scene, multigpu.make_config(0, 1, W, H, 1, 2), multigpu.unique_id())
     with pytest.raises(N.ShrayError):
         me.step([world.frame_params(W, H)] * 3, 0, 0)                                # more frames than the object was made for
     with pytest.raises(N.ShrayError):

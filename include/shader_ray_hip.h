@@ -214,6 +214,14 @@ int shray_device_flat_destroy(shray_device_flat *flat);
 /* Scene ------------------------------------------------------------------ */
 int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene);
 int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height);
+/* How the environment is STORED.  The reference uploads its float image with an unsized GL_RGB internal format
+ * (ray.cpp:508), which most drivers resolve to 8-bit normalized fixed point: values are clamped to [0, 1] and kept
+ * in 1/255 steps, mip levels (ray.cpp:509) included -- an "HDR" environment loses everything above 1.
+ * SHRAY_ENV_FLOAT32 (what shray_scene_set_environment uses, and what a literal evaluation of the shader on the
+ * float image sees) keeps the floats; SHRAY_ENV_UNORM8 reproduces the common driver behaviour: every texel, and
+ * every texel of every mip level, passes through c = floor(255 clamp(f, 0, 1) + 0.5), f = c / 255. */
+enum { SHRAY_ENV_FLOAT32 = 0, SHRAY_ENV_UNORM8 = 1 };
+int shray_scene_set_environment_storage(shray_scene *scene, const float *rgb, int width, int height, int storage);
 int shray_scene_destroy(shray_scene *scene);
 /* The HIP device the scene's buffers live on (the device that was current when it was created). */
 int shray_scene_device(const shray_scene *scene, int *device_index);

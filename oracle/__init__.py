@@ -61,6 +61,12 @@ def render(desc, env: np.ndarray, params, width: int, height: int, spp: int = 1,
     return out, dict(zip(names, (int(c) for c in counters)))
 
 
+def set_env_storage(storage: int) -> None:
+    """0 = the environment's floats as given (default); 1 = stored as 8-bit normalized fixed point, mip levels included
+    (what the reference's unsized GL_RGB upload, ray.cpp:508, becomes on most drivers).  Applies to later renders."""
+    load().shray_oracle_set_env_storage(C.c_int(storage))
+
+
 def filmic(c: float) -> float:
     return float(load().shray_oracle_filmic(C.c_float(c)))
 

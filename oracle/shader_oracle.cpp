@@ -207,6 +207,16 @@ struct Scene {
     std::vector<int> mip_w, mip_h;
 };
 
+// How the environment is stored (shray_oracle_set_env_storage): 0 = the floats as given; 1 = 8-bit normalized fixed
+// point, what the reference's unsized GL_RGB upload (ray.cpp:508) becomes on most drivers -- every texel, and every
+// texel of every mip level, passes through c = floor(255 clamp(f, 0, 1) + 0.5), f = c / 255 (GL 3.1 section 2.1.5)
+int g_env_storage = 0;
+float through_unorm8(float f)
+{
+    const float clamped = !(f > 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
+    return std::floor(clamped * 255.0f + 0.5f) / 255.0f;
+}
+
 void build_mips(Scene &sc)
 {
     sc.mip.clear();
@@ -225,7 +235,8 @@ void build_mips(Scene &sc)
                 for (int c = 0; c < 3; c++) {
                     const float a = src[3 * ((size_t)j0 * sw + i0) + c], b = src[3 * ((size_t)j0 * sw + i1) + c];
                     const float cc = src[3 * ((size_t)j1 * sw + i0) + c], d = src[3 * ((size_t)j1 * sw + i1) + c];
-                    dst[3 * ((size_t)j * w + i) + c] = ((a + b) + (cc + d)) * 0.25f;
+                    const float mean = ((a + b) + (cc + d)) * 0.25f;
+                    dst[3 * ((size_t)j * w + i) + c] = g_env_storage == 1 ? through_unorm8(mean) : mean;
                 }
             }
         sc.mip.push_back(std::move(dst));
@@ -804,6 +815,13 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
     scene.boxmax = desc->group_boxmax;
     scene.hitmiss = desc->group_hitmiss;
     scene.objects = desc->group_objects;
+    std::vector<float> stored_env;
+    if (g_env_storage == 1) {
+        stored_env.assign(env_rgb, env_rgb + 3 * (size_t)env_w * env_h);
+        for (float &texel : stored_env)
+            texel = through_unorm8(texel);
+        env_rgb = stored_env.data();
+    }
     scene.env = env_rgb;
     scene.env_w = env_w;
     scene.env_h = env_h;
@@ -888,6 +906,7 @@ void shray_oracle_texture_grad(const float *rgb, int w, int h, float s, float t,
     const vec3 v = texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
+void shray_oracle_set_env_storage(int storage) { g_env_storage = storage; }
 void shray_oracle_schlick(const float cspec[3], const float v[3], const float r[3], float out[3])
 {
     const vec3 f = f_schlick_vr(V(cspec[0], cspec[1], cspec[2]), V(v[0], v[1], v[2]), V(r[0], r[1], r[2]));

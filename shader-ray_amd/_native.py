@@ -15,6 +15,7 @@ DIST_LIB = os.path.join(PKG_DIR, "libshray_dist.so")
 HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
+ENV_FLOAT32, ENV_UNORM8 = 0, 1
 ABI_VERSION = 3   # SHRAY_ABI_VERSION of the header these structures mirror (tests/test_abi.py compares the two)
 
 
@@ -101,6 +102,7 @@ HIP_SYMBOLS = [
     ("shray_frame_params_init", None, [C.POINTER(FrameParams)]),
     ("shray_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("shray_scene_set_environment", C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int]),
+    ("shray_scene_set_environment_storage", C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int]),
     ("shray_scene_destroy", C.c_int, [C.c_void_p]),
     ("shray_scene_device", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("shray_scene_set_kernel", C.c_int, [C.c_void_p, C.c_int]),

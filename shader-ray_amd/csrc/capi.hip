@@ -659,15 +659,33 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     return SHRAY_OK;
 }
 
+// GL's conversion of a float to 8-bit normalized fixed point and back (GL 3.1 section 2.1.5): clamp to [0, 1],
+// c = floor(255 f + 0.5), stored value c / 255; NaN stores 0
+static float through_unorm8(float f)
+{
+    const float clamped = !(f > 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
+    return floorf(clamped * 255.0f + 0.5f) / 255.0f;
+}
+
 int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width, int height)
+{
+    return shray_scene_set_environment_storage(scene, rgb, width, height, SHRAY_ENV_FLOAT32);
+}
+
+int shray_scene_set_environment_storage(shray_scene *scene, const float *rgb, int width, int height, int storage)
 {
     if (!scene || !rgb || width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "bad environment (%p, %d x %d)", (const void *)rgb, width, height);
+    if (storage != SHRAY_ENV_FLOAT32 && storage != SHRAY_ENV_UNORM8)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "environment storage %d (SHRAY_ENV_FLOAT32 or SHRAY_ENV_UNORM8)", storage);
     HIP_TRY(hipSetDevice(scene->device));
     // level 0 followed by its mip chain (2x2 box filter, ((a+b)+(c+d))*0.25, dimensions max(1, n/2)),
     // the pyramid the reference asks GL for with glGenerateMipmap (ray.cpp:509); only the which == 1
     // view reads levels above 0
     std::vector<float> pyramid(rgb, rgb + (size_t)width * height * 3);
+    if (storage == SHRAY_ENV_UNORM8)
+        for (float &texel : pyramid)
+            texel = through_unorm8(texel);
     SceneView &v = scene->view;
     v.mip_levels = 0;
     size_t level_start = 0;
@@ -691,7 +709,8 @@ int shray_scene_set_environment(shray_scene *scene, const float *rgb, int width,
                 for (int c = 0; c < 3; c++) {
                     const float a = src[3 * ((size_t)j0 * w + i0) + c], b = src[3 * ((size_t)j0 * w + i1) + c];
                     const float cc = src[3 * ((size_t)j1 * w + i0) + c], d = src[3 * ((size_t)j1 * w + i1) + c];
-                    dst[3 * ((size_t)j * nw + i) + c] = ((a + b) + (cc + d)) * 0.25f;
+                    const float mean = ((a + b) + (cc + d)) * 0.25f;
+                    dst[3 * ((size_t)j * nw + i) + c] = storage == SHRAY_ENV_UNORM8 ? through_unorm8(mean) : mean;   // every level is stored
                 }
             }
         level_start = next_start;

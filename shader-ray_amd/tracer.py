@@ -39,12 +39,13 @@ class Scene:
         except Exception:
             pass
 
-    def set_environment(self, rgb: np.ndarray):
-        """`rgb` is [height, width, 3] float32, row 0 = straight down (texture t = 0)."""
+    def set_environment(self, rgb: np.ndarray, storage: int = N.ENV_FLOAT32):
+        """`rgb` is [height, width, 3] float32, row 0 = straight down (texture t = 0).  storage = ENV_UNORM8 keeps
+        it the way most drivers keep the reference's unsized GL_RGB upload (ray.cpp:508): 8 bits, clamped to [0, 1]."""
         rgb = np.ascontiguousarray(rgb, dtype=np.float32)
         h, w, c = rgb.shape
         assert c == 3
-        N.check(self._lib.shray_scene_set_environment(self._handle, rgb.ctypes.data_as(N.c_float_p), w, h))
+        N.check(self._lib.shray_scene_set_environment_storage(self._handle, rgb.ctypes.data_as(N.c_float_p), w, h, storage))
 
     def set_kernel(self, kernel_id: int):
         N.check(self._lib.shray_scene_set_kernel(self._handle, kernel_id))

@@ -552,3 +552,27 @@ def test_nan_candidate_is_accepted_and_resets_the_comparison(pkg, oracle_mod):
             want, _ = oracle_mod.render(nan_leaf_scene(tail).desc, env, p, 16, 16, 1)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), order
             assert not np.isnan(got).any()
+
+
+def test_unorm8_environment_storage(pkg, oracle_mod):
+    """The reference uploads its environment with an unsized GL_RGB format (ray.cpp:508): on most drivers 8 bits,
+    clamped to [0, 1].  With that storage an env-only pixel is the tone-mapped bilinear sample of the QUANTISED image:
+    values above 1 are gone, everything sits on 1/255 steps before filtering."""
+    env = pkg.scenes.environment_hdr_sky(64)
+    assert env.max() > 1.5                      # the sun is above 1: float storage keeps it
+    hand = far_away_triangle()
+    p = default_params(pkg, 24, 16)
+    try:
+        oracle_mod.set_env_storage(1)
+        got, _ = oracle_mod.render(hand.desc, env, p, 24, 16, 1)
+    finally:
+        oracle_mod.set_env_storage(0)
+    plain, _ = oracle_mod.render(hand.desc, env, p, 24, 16, 1)
+    q = (np.floor(np.clip(env, 0.0, 1.0).astype(np.float32) * np.float32(255.0) + np.float32(0.5)) / np.float32(255.0)).astype(np.float32)
+    assert len(np.unique(q)) <= 256 and q.max() <= 1.0
+    want, _ = oracle_mod.render(hand.desc, q, p, 24, 16, 1)       # float storage of the pre-quantised image
+    assert np.array_equal(got, want) and not np.array_equal(got, plain)
+    for (px, py) in ((3, 2), (12, 8), (20, 13)):
+        d = pixel_dir64(p, px, py, 24, 16)
+        ref = filmic64(env_bilinear64(q.astype(np.float64), d))
+        assert np.allclose(got[py, px, :3], ref, rtol=2e-5, atol=2e-6), (px, py)

@@ -107,7 +107,8 @@ struct shray_scene {
     int stack_levels = 1;
 
     DeviceBuffer positions, normals16, normals32, boxmin, boxmax, hitmiss, objects;
-    DeviceBuffer packed_nodes, packed_tris;
+    DeviceBuffer packed_nodes, packed_tris, pair_nodes;
+    uint32_t max_leaf_count = 0;     // the largest leaf: the pair records keep min(count, 127) (packed_layout.h)
     DeviceBuffer env;
     DeviceBuffer counters;
     DeviceBuffer patch_order;        // permutation of patch indices for the stack kernel (optional)
@@ -447,8 +448,31 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 // ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
 // tally / policy_frames: shray_render_counters_timed -- the instance a launch of `policy_frames` frames would run, with
 // per-ray work tallies
+// Which launches of the stack kernel test both children of a node per turn (wave_traversal.h: inner_stage_pair).  The
+// pair form issues the same arithmetic and the same loads as the one-visit form but about 0.6 of its dependent round
+// trips, for a fatter turn: it pays where a launch is bound by the latency of its longest rays, not by issue slots.
+// SHRAY_PAIR_POLICY: 0 = only when the scene asks for it (shray_scene_set_kernel(scene, 3)), 1 = also for the launches
+// named below, 2 = every launch that can.
+#ifndef SHRAY_PAIR_POLICY
+#define SHRAY_PAIR_POLICY 0
+#endif
+bool pair_policy(const shray_scene *scene, const FrameView *views, int count, int frames_in_launch)
+{
+    if (!scene->pair_nodes.p)
+        return false;
+    // a pair record keeps min(triangle count, 127): exact whenever the leaf cap or the largest leaf stays below that
+    for (int k = 0; k < count; k++)
+        if (scene->max_leaf_count > 126u && (uint32_t)views[k].max_leaf_tests > 126u)
+            return false;
+    if (scene->kernel_id == 3 || SHRAY_PAIR_POLICY == 2)
+        return true;
+    const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
+    const bool latency_launch = frames_in_launch == 1 && views[0].spp == 1;
+    return SHRAY_PAIR_POLICY == 1 && (divergent_scene || latency_launch);
+}
+
 int launch_stack_views(shray_scene *scene, const FrameView *views, int count, float4 *d_out, size_t frame_stride,
-                       hipStream_t stream, DeviceCounters *tally = nullptr, int policy_frames = 0)
+                       hipStream_t stream, DeviceCounters *tally = nullptr, int policy_frames = 0, bool tally_full_walk = false)
 {
     if (views[0].total_patches == 0)
         return SHRAY_OK;
@@ -478,7 +502,8 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
         : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
                              leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp), d_out, frame_stride, stream,
-                             scene->stack_levels, tally);
+                             scene->stack_levels, tally, plain_view && pair_policy(scene, views, count, policy_frames > 0 ? policy_frames : count),
+                             tally_full_walk);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
@@ -495,6 +520,9 @@ int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters
     hipError_t e;
     if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
         return launch_stack_views(s, &fr, 1, d_out, 0, stream);
+    const bool view_instance = fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5;
+    if (s->kernel_id == 3 && s->packed_ok && d_counters && !fr.patch_order && !view_instance && pair_policy(s, &fr, 1, 1))
+        return launch_stack_views(s, &fr, 1, d_out, 0, stream, d_counters, 0, true);   // the pair traversal's own counting twin
     else if (s->kernel_id == 2 && s->packed_ok && !fr.patch_order &&
              !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5))
         e = launch_pool(s->view, fr, d_out, d_counters, stream, s->stack_levels);
@@ -621,6 +649,46 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         HIP_TRY(s->packed_nodes.upload(nodes.data(), nodes.size() * sizeof(PackedNode)));
         HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
         s->view.packed_root = packed_root;
+        // sibling pairs for the pair traversal: the record of an inner node holds both children's boxes and links
+        {
+            std::vector<PackedPair> pairs(nodes.size());
+            memset(pairs.data(), 0, pairs.size() * sizeof(PackedPair));
+            uint32_t largest = 0;
+            auto link_of = [&](uint32_t child, uint32_t *info) {
+                const PackedNode &c = nodes[child];
+                if (c.b & kLeafFlag) {
+                    const uint32_t count = c.b & ~kLeafFlag;
+                    largest = std::max(largest, count);
+                    *info = c.a;
+                    return child | (std::min(count, kPairCountMask) << kPairCountShift) | kLeafFlag;
+                }
+                *info = 0;
+                return child | ((c.a >> 30) << kPairAxisShift);
+            };
+            for (size_t k = 0; k < nodes.size(); k++) {
+                const PackedNode &pn = nodes[k];
+                if (pn.b & kLeafFlag) {
+                    largest = std::max(largest, pn.b & ~kLeafFlag);
+                    continue;
+                }
+                const uint32_t pos = pn.a & kChildMask, neg = pn.b;
+                PackedPair &pp = pairs[k];
+                memcpy(pp.lo0, nodes[neg].lo, 12);
+                memcpy(pp.hi0, nodes[neg].hi, 12);
+                pp.link0 = link_of(neg, &pp.info0);
+                memcpy(pp.lo1, nodes[pos].lo, 12);
+                memcpy(pp.hi1, nodes[pos].hi, 12);
+                pp.link1 = link_of(pos, &pp.info1);
+            }
+            HIP_TRY(s->pair_nodes.upload(pairs.data(), pairs.size() * sizeof(PackedPair)));
+            s->max_leaf_count = largest;
+            uint32_t dummy = 0;
+            s->view.pair_root_link = link_of(packed_root, &dummy);
+            uint32_t bits = 1;
+            while ((1ull << bits) < nodes.size())
+                bits++;
+            s->view.pair_index_bits = bits;
+        }
         // operand-range condition of exact_div.h on the scene's side: every box coordinate
         // is zero or has magnitude in [2^-70, 2^60)
         bool coords_ok = true;
@@ -652,6 +720,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     v.tree_root = (float)desc->tree_root;
     v.packed_nodes = s->packed_nodes.p;
     v.packed_tris = s->packed_tris.p;
+    v.pair_nodes = s->pair_nodes.p;
     v.env = nullptr;
     v.env_w = v.env_h = 0;
 
@@ -743,8 +812,8 @@ int shray_scene_device(const shray_scene *scene, int *device_index)
 
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
-    if (!scene || kernel_id < 0 || kernel_id > 2)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = pool)", kernel_id);
+    if (!scene || kernel_id < 0 || kernel_id > 3)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = pool, 3 = stack with pair turns)", kernel_id);
     if (kernel_id != 1 && !scene->packed_ok)
         return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
                     "literal threaded kernel (1) can run it");
@@ -1018,7 +1087,7 @@ int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *pa
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "frames_per_launch %d (1..%d)", frames_per_launch, SHRAY_MAX_BATCH);
     const bool view = params->which == 1 || params->which == 2 || params->which == 3 || params->which == 5;
     // only the stack kernel's convergent instances have a timed form of their own; everything else is timed as it counts
-    if (scene->kernel_id != 0 || !scene->packed_ok || view || scene->patch_order.p)
+    if ((scene->kernel_id != 0 && scene->kernel_id != 3) || !scene->packed_ok || view || scene->patch_order.p)
         return shray_render_counters(scene, params, width, height, spp, rgba_out_host, counters);
     if (!scene->view.env)
         return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");

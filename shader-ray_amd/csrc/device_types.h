@@ -37,6 +37,9 @@ struct SceneView {
     const void *packed_tris;    // PackedTri[triangle_count]
     uint32_t packed_root;
     uint32_t exact_div_ok;      // every box coordinate is 0 or in [2^-70, 2^60): exact_div.h applies
+    const void *pair_nodes;     // PackedPair[group_count] (packed_layout.h), or nullptr: the pair traversal is not available
+    uint32_t pair_root_link;    // the root as a pair link: index | axis << 29 | leaf flag
+    uint32_t pair_index_bits;   // IB: bits of the largest packed node index; a stack word keeps 29 - IB bits of r0
 
     const float *env;   // RGB f32, row 0 = t = 0 (straight down); level 0 of the pyramid below
     int32_t env_w, env_h;

@@ -69,10 +69,10 @@ static bool metal(const FrameView &fr)
 }
 static bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
 
-template <bool DEAL, int BLOCK = kBlock>
-__device__ __forceinline__ StackTraversal<BLOCK, DEAL> make_traversal(uint32_t *lds, int stack_levels, const SceneView &sc)
+template <bool DEAL, int BLOCK = kBlock, bool PAIR = false>
+__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR> make_traversal(uint32_t *lds, int stack_levels, const SceneView &sc)
 {
-    StackTraversal<BLOCK, DEAL> trav;
+    StackTraversal<BLOCK, DEAL, PAIR> trav;
     trav.stack = lds + threadIdx.x;
     trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x & ~63u);
 #if SHRAY_LDS_TOP
@@ -116,12 +116,16 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // Batch forms: workgroup (x, y) renders patch x of frame y.  Workgroups are dispatched x-fastest, so
 // frame 0 starts first and later frames fill the SIMDs its long-running waves leave idle.
 // DEAL = false is the throughput instance (several spp == 1 frames per launch): one wave more per SIMD, plain leaf loop
-template <bool ONE_SAMPLE, bool METAL, bool DEAL, bool TALLY>
+// TALLY: 0 = the timed kernels; 1 = the same form with per-ray work tallies (what the timed form does); 2 = tallies of
+// the reference's walk (one lane per pixel, every shadow ray to its end) -- the counting twin of the pair traversal.
+// PAIR: both children of a node per turn (wave_traversal.h)
+template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR>
 __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,
                                                  int stack_levels, int frame_count_arg, DeviceCounters *counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    StackTraversal<kBatchBlock, DEAL> trav = make_traversal<DEAL, kBatchBlock>(lds_stack, stack_levels, sc);
+    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR>;
+    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR>(lds_stack, stack_levels, sc);
 #if SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES
     // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
     // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
@@ -135,11 +139,11 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
         frame = rest % frame_count;
         block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
     }
-    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, TALLY, ONE_SAMPLE, METAL, TALLY>(sc, frames[frame], out + (size_t)frame * frame_stride,
-                                                                                            counters, trav, block_index);
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
+                                                                               block_index);
 #else
-    trace_pixels_uniform<StackTraversal<kBatchBlock, DEAL>, TALLY, ONE_SAMPLE, METAL, TALLY>(sc, frames[blockIdx.y],
-                                                                                            out + (size_t)blockIdx.y * frame_stride, counters, trav);
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
+                                                                               counters, trav);
 #endif
 }
 
@@ -148,7 +152,23 @@ __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE
                                                                                                float4 *out, size_t frame_stride, int stack_levels,
                                                                                                int frame_count_arg)
 {
-    stack_batch_body<ONE_SAMPLE, METAL, DEAL, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+    stack_batch_body<ONE_SAMPLE, METAL, DEAL, 0, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+}
+
+// The pair traversal (dealt leaf stage): for launches that are bound by dependent round trips -- a lone frame, a tree
+// larger than the L2 (capi.hip: pair_policy)
+#ifndef SHRAY_MIN_WAVES_PAIR
+#define SHRAY_MIN_WAVES_PAIR 6
+#endif
+#ifndef SHRAY_MIN_WAVES_PAIR_GENERAL
+#define SHRAY_MIN_WAVES_PAIR_GENERAL 5
+#endif
+template <bool ONE_SAMPLE, bool METAL>
+__global__ void __launch_bounds__(kBatchBlock, METAL ? SHRAY_MIN_WAVES_PAIR : SHRAY_MIN_WAVES_PAIR_GENERAL)
+    trace_stack_batch_pair_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride, int stack_levels,
+                                  int frame_count_arg)
+{
+    stack_batch_body<ONE_SAMPLE, METAL, true, 0, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
 }
 
 // The same instances with per-ray work tallies (shray_render_counters_timed): what the TIMED form does -- sample lanes,
@@ -159,7 +179,15 @@ __global__ void __launch_bounds__(kBatchBlock, 4) trace_stack_batch_tally_kernel
                                                                                  size_t frame_stride, int stack_levels, int frame_count_arg,
                                                                                  DeviceCounters *counters)
 {
-    stack_batch_body<ONE_SAMPLE, METAL, DEAL, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, counters);
+    stack_batch_body<ONE_SAMPLE, METAL, DEAL, 1, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, counters);
+}
+// ... and of the pair traversal: FULL_WALK = the reference's walk (its counting twin), else the timed form
+template <bool ONE_SAMPLE, bool METAL, bool FULL_WALK>
+__global__ void __launch_bounds__(kBatchBlock, 4) trace_stack_batch_pair_tally_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out,
+                                                                                      size_t frame_stride, int stack_levels, int frame_count_arg,
+                                                                                      DeviceCounters *counters)
+{
+    stack_batch_body<ONE_SAMPLE, METAL, true, FULL_WALK ? 2 : 1, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, counters);
 }
 
 template <bool DIFF>
@@ -181,12 +209,13 @@ static size_t stack_lds_bytes(int stack_levels, int block = kBlock)
 // `deal`: the dealt leaf stage instead of the plain one (capi.hip: leaf_stage_policy)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
-                              DeviceCounters *tally)
+                              DeviceCounters *tally, bool pair, bool tally_full_walk)
 {
     // the view instances run 256-thread workgroups (a patch each), the convergent ones kBatchBlock-thread workgroups
     const bool view_instance = !all_plain;
     // one-wave workgroups: four per patch, times the lanes per pixel of a multi-sample frame (uniform_driver.h)
-    const unsigned int sample_lanes = (kBatchBlock == 64 && !one_sample(first)) ? (1u << (first.sample_log_x + first.sample_log_y)) : 1u;
+    const unsigned int sample_lanes = (kBatchBlock == 64 && !one_sample(first) && !(tally && tally_full_walk))
+                                          ? (1u << (first.sample_log_x + first.sample_log_y)) : 1u;   // (the reference's walk: one lane per pixel)
     const unsigned int per_patch = view_instance ? 1u : (unsigned int)(kBlock / kBatchBlock) * sample_lanes;
     const unsigned int grid_patches = (SHRAY_WAVE_BLOCKS == 2 && !view_instance) ? ((first.total_patches + 7u) & ~7u) : first.total_patches;
     // convergent instances: the frames of the launch interleaved along grid.x (see the kernel); the view instances keep grid.y = frame
@@ -201,6 +230,25 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
 #define SHRAY_LAUNCH_VIEW_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels)
 #define SHRAY_LAUNCH_BATCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels, count)
 #define SHRAY_LAUNCH_TALLY(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels, count, tally)
+#define SHRAY_LAUNCH_PAIR_TALLY(O, M)                                                                    \
+    do {                                                                                                \
+        if (tally_full_walk)                                                                            \
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_pair_tally_kernel<O, M, true>));                      \
+        else                                                                                            \
+            SHRAY_LAUNCH_TALLY((trace_stack_batch_pair_tally_kernel<O, M, false>));                     \
+    } while (0)
+    if (tally && all_plain && pair) {
+        if (one && metallic)
+            SHRAY_LAUNCH_PAIR_TALLY(true, true);
+        else if (one)
+            SHRAY_LAUNCH_PAIR_TALLY(true, false);
+        else if (metallic)
+            SHRAY_LAUNCH_PAIR_TALLY(false, true);
+        else
+            SHRAY_LAUNCH_PAIR_TALLY(false, false);
+        return hipGetLastError();
+    }
+#undef SHRAY_LAUNCH_PAIR_TALLY
     if (tally && all_plain) {   // the same choice of instance as below, with tallies
         if (one && metallic && deal)
             SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, true, true>));
@@ -227,6 +275,15 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
         SHRAY_LAUNCH_VIEW_BATCH(trace_stack_view_batch_kernel<true>);
     else if (!all_plain)
         SHRAY_LAUNCH_VIEW_BATCH(trace_stack_view_batch_kernel<false>);
+    // `pair` (capi.hip: pair_policy): both children per node turn, dealt leaf stage
+    else if (pair && one && metallic)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<true, true>));
+    else if (pair && one)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<true, false>));
+    else if (pair && metallic)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<false, true>));
+    else if (pair)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<false, false>));
     // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of each class of instances
     else if (one && metallic && deal)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, true>));

@@ -42,6 +42,29 @@ struct PackedTri {
 };
 static_assert(sizeof(PackedTri) == 36, "PackedTri must be 36 bytes");
 
+// Sibling pairs for the pair traversal (wave_traversal.h: inner_stage_pair): the record of inner node N holds the
+// boxes of BOTH its children, so that one memory round trip serves two of the reference's visits.  64 B, indexed like
+// PackedNode (only inner nodes' records are read):
+//     { neg.boxmin, neg.link } { neg.boxmax, neg.info } { pos.boxmin, pos.link } { pos.boxmax, pos.info }
+//   link = child index (bits 21:0) | min(triangle count, 127) << 22 (leaf) | the child's split axis << 29 (branch)
+//          | 0x80000000 (leaf);   info = the leaf's first triangle
+// A ray's stack word for a pending far child is the low kPairLinkBits' worth of that link squeezed to
+// (index | axis << IB | leaf << (IB + 2)), IB = bits of the largest node index, with the child's box entry distance r0
+// truncated to the remaining 29 - IB high bits above it (all ones: the box range was empty) -- see lane_pop.
+struct PackedPair {
+    float lo0[3];
+    uint32_t link0;
+    float hi0[3];
+    uint32_t info0;
+    float lo1[3];
+    uint32_t link1;
+    float hi1[3];
+    uint32_t info1;
+};
+static_assert(sizeof(PackedPair) == 64, "PackedPair must be 64 bytes");
+constexpr uint32_t kPairIndexMask = 0x003fffffu;
+constexpr uint32_t kPairCountShift = 22, kPairCountMask = 0x7fu, kPairAxisShift = 29;
+
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kChildMask = 0x3fffffffu;
 constexpr uint32_t kNoNode = 0xffffffffu;

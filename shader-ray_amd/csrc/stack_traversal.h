@@ -39,7 +39,8 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #define SHRAY_KEEP_FLOOR 2
 #endif
 // DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
-template <int BLOCK, bool DEAL = true>
+// PAIR: both children of a node per turn (wave_traversal.h: inner_stage_pair); convergent form only
+template <int BLOCK, bool DEAL = true, bool PAIR = false>
 struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
@@ -67,6 +68,16 @@ struct StackTraversal {
         LaneTraversal t;
         lane_begin<COUNT>(sc, fr, t, stack, P, D, rc, has_ray);
         int state = has_ray ? LT_WALK : LT_ENDED;
+        if (PAIR) {
+            // the root's visit (its own box, fs:395's first iteration) is made by the first retest stage
+            t.node = sc.pair_root_link;
+            state = has_ray ? LT_RETEST : LT_ENDED;
+            if (COUNT && has_ray) {
+                rc.node_visits++;
+                if (sc.pair_root_link & kLeafFlag)
+                    rc.leaf_visits++;
+            }
+        }
         run<COUNT, true, ANY_HIT && (!COUNT || TIMED_FORM)>(sc, fr, t, state, rc);
         hit = t.hit;
         return traced;
@@ -95,7 +106,11 @@ struct StackTraversal {
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
             const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
-            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG, top);
+            if (PAIR) {
+                inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
+                retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);
+            } else
+                inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG, top);
 #else
             inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
 #endif
@@ -103,9 +118,9 @@ struct StackTraversal {
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
             if (SHRAY_DEAL_LEAVES && DEAL && CONVERGED)
-                leaf_stage_dealt<COUNT, BLOCK>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
+                leaf_stage_dealt<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             else
-                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
+                leaf_stage<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
             if (ANY_HIT && state != LT_ENDED && t.hit.t < kFar)
                 state = LT_ENDED;   // a hit: the shadow query is answered (a capped ray, t = -1, has ended already)
 #ifdef SHRAY_DIAGNOSTICS

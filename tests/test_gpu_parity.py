@@ -17,7 +17,9 @@ from helpers import assert_images_match, default_params, single_leaf_scene
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KERNELS = [0, 1, 2]   # 0 = packed stack kernel, 1 = literal threaded kernel, 2 = pool kernel (waves merge mid-traversal)
+# 0 = packed stack kernel, 1 = literal threaded kernel, 2 = pool kernel (waves merge mid-traversal),
+# 3 = stack kernel with both children of a node per turn (its counters come from its own counting twin)
+KERNELS = [0, 1, 2, 3]
 
 
 @pytest.fixture(scope="module")
@@ -254,7 +256,7 @@ def test_tile_sets_reassemble_to_the_full_frame(pkg, gpu, bunny):
     params = world.frame_params(W, H, material=0)
     full = scene.render(params, W, H, 1)
     N = pkg._native
-    for kernel, (tw, th, stride) in [(k, g) for k in (0, 2) for g in ((32, 32, 3), (16, 48, 2), (64, 32, 8))]:
+    for kernel, (tw, th, stride) in [(k, g) for k in (0, 2, 3) for g in ((32, 32, 3), (16, 48, 2), (64, 32, 8))]:
         scene.set_kernel(kernel)
         parts = []
         for phase in range(stride):
@@ -595,7 +597,7 @@ env = pkg.scenes.environment_hdr_sky(64)
 params = world.frame_params(96, 72, material=6)
 want, cpu = oracle.render(desc, env, params, 96, 72, 1)
 scene = pkg.Scene(desc, env, device=0)
-for kernel in (0, 1, 2):
+for kernel in (0, 1, 2, 3):
     scene.set_kernel(kernel)
     got, gpu = scene.render_counters(params, 96, 72, 1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), kernel

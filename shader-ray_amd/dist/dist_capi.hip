@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -163,6 +164,8 @@ struct shray_dist_hub {
     Mailbox &box(int src, int dst) { return *boxes[(size_t)src * world + dst]; }
     ~shray_dist_hub()
     {
+        if (device >= 0)
+            (void)hipSetDevice(device);
         for (auto &b : boxes)
             for (Slot &s : b->slots) {
                 if (s.staging)
@@ -220,7 +223,10 @@ struct LoopbackTransport : Transport {
     {
         shray_dist_hub::Mailbox &mb = hub->box(peer, rank);
         std::unique_lock<std::mutex> lock(mb.m);
-        mb.cv.wait(lock, [&] { return !mb.pending.empty(); });
+        // a step is collective: the peer's send is on its way unless that rank failed or was never started
+        if (!mb.cv.wait_for(lock, std::chrono::seconds(60), [&] { return !mb.pending.empty(); }))
+            return fail(SHRAY_ERR_DEVICE, "loopback: rank %d waited 60 s for a transfer from rank %d (did that rank's step fail, or was it "
+                        "called with another frame count?)", rank, peer);
         const int which = mb.pending.front();
         mb.pending.pop_front();
         shray_dist_hub::Slot &s = mb.slots[which];

@@ -61,6 +61,52 @@ def render(desc, env: np.ndarray, params, width: int, height: int, spp: int = 1,
     return out, dict(zip(names, (int(c) for c in counters)))
 
 
+GLSL_REF_LIB = os.path.join(HERE, "_ref", "libglsl_ref.so")
+REFERENCE_DIR = os.environ.get("SHRAY_REFERENCE_DIR", "/root/reference")
+MESA_SOFTWARE_DRIVER = os.environ.get("SHRAY_MESA_DRIVER", "/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
+_glsl = None
+
+
+def reference_shader_available() -> bool:
+    """The reference's GLSL can run here: its sources, Mesa's software driver and the harness are present."""
+    return (os.path.exists(GLSL_REF_LIB) and os.path.exists(os.path.join(REFERENCE_DIR, "raytracer.es.fs"))
+            and os.path.exists(MESA_SOFTWARE_DRIVER))
+
+
+def render_reference_shader(desc, env: np.ndarray, params, width: int, height: int, background_mode: int = 0,
+                            anisotropy: float | None = None):
+    """One frame of the REFERENCE'S OWN shaders (raytracer.vs + raytracer.es.fs, read from the reference tree, compiled
+    unmodified as "#version 140" by Mesa's llvmpipe on the CPU; oracle/glsl_ref/glsl_ref.cpp restates ray.cpp's GL
+    calls around them).  RGBA float32 [height, width, 4], row 0 = bottom, plus the harness's log (GL version, shader
+    logs).  background_mode 0: sized GL_RGB32F; 1: the reference's literal unsized GL_RGB (ray.cpp:508).  anisotropy:
+    override of ray.cpp:506's 4.0 (None = 4.0).  Only tests/golden/make_glsl_reference.py and the live check of
+    tests/test_reference_shader.py call this."""
+    global _glsl
+    if _glsl is None:
+        _glsl = C.CDLL(GLSL_REF_LIB)
+        _glsl.shray_glsl_ref_render.restype = C.c_int
+    env = np.ascontiguousarray(env, dtype=np.float32)
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    log = C.create_string_buffer(1 << 16)
+    previous = os.environ.get("SHRAY_GLSL_REF_ANISOTROPY")
+    if anisotropy is not None:
+        os.environ["SHRAY_GLSL_REF_ANISOTROPY"] = repr(float(anisotropy))
+    try:
+        rc = _glsl.shray_glsl_ref_render(REFERENCE_DIR.encode(), MESA_SOFTWARE_DRIVER.encode(), C.byref(desc),
+                                         env.ctypes.data_as(C.c_void_p), C.c_int(env.shape[1]), C.c_int(env.shape[0]),
+                                         C.c_int(background_mode), C.byref(params), C.c_int(width), C.c_int(height),
+                                         out.ctypes.data_as(C.c_void_p), log, C.c_int(len(log)))
+    finally:
+        if anisotropy is not None:
+            if previous is None:
+                del os.environ["SHRAY_GLSL_REF_ANISOTROPY"]
+            else:
+                os.environ["SHRAY_GLSL_REF_ANISOTROPY"] = previous
+    if rc != 0:
+        raise RuntimeError(f"the reference shaders did not run (code {rc}): {log.value.decode(errors='replace')}")
+    return out, log.value.decode(errors="replace")
+
+
 def set_env_storage(storage: int) -> None:
     """0 = the environment's floats as given (default); 1 = stored as 8-bit normalized fixed point, mip levels included
     (what the reference's unsized GL_RGB upload, ray.cpp:508, becomes on most drivers).  Applies to later renders."""

@@ -1,0 +1,123 @@
+"""The inputs of the reference-shader fixtures (tests/golden/glsl_reference/*.npz).
+
+Each case is built from things every box has -- the committed scene files, the package's deterministic scene and
+environment generators, the hand-built known-answer scenes of test_oracle_kat.py -- so that the generator
+(tests/golden/make_glsl_reference.py, which runs the REFERENCE'S OWN GLSL in the one container that holds the reference
+tree) and the tests (which run the oracle / the HIP kernels anywhere) feed exactly the same bytes; the fixture stores
+the reference's output and a hash of these inputs.
+
+A case: dict(scene=(desc, keepalive), env=float32 [h, w, 3], params=FrameParams, width, height,
+             background_mode=0 | 1, anisotropy=None | float, env_storage=0 | 1 (what the ORACLE is told),
+             max_rel=largest relative difference any pixel may show, bad_fraction=share of pixels that may sit outside
+             1e-4 relative (the GL compiler's own pow / atan / acos are a few 1e-5 off the oracle's explicit sequences),
+             recorded=True: compared and reported but not asserted, with `why`)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+
+import helpers
+from helpers import default_params, single_leaf_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FIXTURES = os.path.join(GOLDEN, "glsl_reference")
+
+
+def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, **more):
+    world = pkg.World(path)
+    view = world.default_view()
+    view.which = which
+    for _ in range(rotate):
+        pkg.host.trackball_motion(view.object_rotation, 0.11, -0.07)
+        pkg.host.trackball_motion(view.light_rotation, -0.05, 0.09)
+    params = world.frame_params(width, height, view, material=material)
+    return dict(scene=(world.flatten(), world), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=width,
+                height=height, background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, recorded=False, why="",
+                **more)
+
+
+def _hand_case(pkg, hand, env, params, width, height, **more):
+    return dict(scene=(hand.desc, hand), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=width, height=height,
+                background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, recorded=False, why="", **more)
+
+
+def cases(pkg):
+    """name -> case, in a fixed order."""
+    import test_oracle_kat as kat
+    lobed = os.path.join(GOLDEN, "lobed_528.trisrc")
+    quads = os.path.join(GOLDEN, "quads_nonormals.obj")
+    constant = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    sky = pkg.scenes.environment_hdr_sky(128)
+    out = {}
+    # -- traversal, intersection, shading, Fresnel, shadow rays, tone map: a constant environment takes the texture
+    #    filter out of the picture (every lookup returns the same texel whatever the driver's filter does)
+    out["lobed_gold_constant"] = _world_case(pkg, lobed, constant, 96, 64, 0)
+    out["lobed_plaster_constant"] = _world_case(pkg, lobed, constant, 96, 64, 6)
+    out["lobed_plaster_constant_rotated"] = _world_case(pkg, lobed, constant, 96, 64, 6, rotate=2)
+    out["quads_obj_chrome_constant"] = _world_case(pkg, quads, constant, 80, 80, 1)
+    # -- the environment lookup (lat-long coordinates, bilinear, wrap): a smooth HDR sky.  The reference asks for 4x
+    #    anisotropy (ray.cpp:506) and calls textureGrad with ZERO derivatives (fs:153), a corner GL leaves undefined
+    #    (Pmax / Pmin = 0 / 0); the oracle's rule is level-0 bilinear, which is what this driver does at anisotropy 1.
+    out["lobed_gold_sky_isotropic"] = _world_case(pkg, lobed, sky, 96, 64, 0, )
+    out["lobed_gold_sky_isotropic"]["anisotropy"] = 1.0
+    out["lobed_plaster_sky_isotropic_rotated"] = _world_case(pkg, lobed, sky, 96, 64, 6, rotate=1)
+    out["lobed_plaster_sky_isotropic_rotated"]["anisotropy"] = 1.0
+    out["lobed_gold_sky_anisotropic4"] = _world_case(pkg, lobed, sky, 96, 64, 0)
+    out["lobed_gold_sky_anisotropic4"].update(recorded=True, why="the driver's anisotropic filter at zero derivatives (undefined in GL)")
+    # -- the reference's literal background upload: unsized GL_RGB with float data (ray.cpp:508); this driver stores it
+    #    as 8-bit normalized -- the storage rule SHRAY_ENV_UNORM8 / oracle.set_env_storage(1) states
+    out["lobed_gold_sky_unsized_rgb"] = _world_case(pkg, lobed, sky, 96, 64, 0)
+    out["lobed_gold_sky_unsized_rgb"].update(background_mode=1, anisotropy=1.0, env_storage=1, max_rel=2e-2, bad_fraction=1.0,
+                                             why="8-bit texels are filtered with 8-bit weights by this driver: agreement to ~1e-2, "
+                                                 "ten times that where the sun shows with float storage")
+    # -- the shader's debug views (fs:135-149, :642-673)
+    for which in (2, 3, 5):
+        c = _world_case(pkg, lobed, sky, 64, 48, 0, which=which)
+        c["anisotropy"] = 1.0
+        if which != 5:   # differences of nearly equal lookup coordinates, times 100: the compiler's atan / acos show
+            c.update(max_rel=1e-2, bad_fraction=1.0, why="ill-conditioned debug view (100 x a difference of lookup coordinates)")
+        out[f"lobed_gold_sky_which{which}"] = c
+    c = _world_case(pkg, lobed, sky, 64, 48, 0, which=1)
+    c.update(recorded=True, why="which == 1 samples through the driver's own trilinear / anisotropic filter")
+    out["lobed_gold_sky_which1"] = c
+    # -- the analytic known-answer scenes of test_oracle_kat.py, through the real shader
+    out["kat_env_only"] = _hand_case(pkg, kat.far_away_triangle(), sky, default_params(pkg, 48, 32), 48, 32, )
+    out["kat_env_only"]["anisotropy"] = 1.0
+    out["kat_mirror_quad"] = _hand_case(pkg, single_leaf_scene(kat.mirror_quad()), constant, default_params(pkg, 40, 24, zoom=3.0), 40, 24)
+    out["kat_plaster_quad"] = _hand_case(pkg, single_leaf_scene(kat.mirror_quad()), constant, default_params(pkg, 40, 24, zoom=3.0, material=6), 40, 24)
+    out["kat_iteration_cap_401"] = _hand_case(pkg, kat.chain_scene(401), constant, default_params(pkg, 8, 8), 8, 8)
+    out["kat_iteration_cap_400"] = _hand_case(pkg, kat.chain_scene(400), constant, default_params(pkg, 8, 8), 8, 8)
+    tris = [[[-5, -5, -float(k)], [5, -5, -float(k)], [0, 5, -float(k)]] for k in range(10)] + [[[-5, -5, 1.0], [5, -5, 1.0], [0, 5, 1.0]]]
+    out["kat_eleven_triangle_leaf"] = _hand_case(pkg, single_leaf_scene(tris), constant, default_params(pkg, 16, 16), 16, 16)
+    for k, order in enumerate((("nan", 0.1), (0.1, "nan"), (0.1, "nan", -0.1), (0.2, 0.1, 0.0, "nan", -0.1, -0.2, 0.15))):
+        p = default_params(pkg, 16, 16, zoom=3.0)
+        out[f"kat_nan_candidate_{k}"] = _hand_case(pkg, kat.nan_leaf_scene(order), constant, p, 16, 16)
+        out[f"kat_nan_candidate_{k}"].update(recorded=True, why="GLSL leaves operations on NaN undefined: the oracle and the kernels give "
+                                             "the shader's comparisons IEEE semantics, this driver does something else")
+    return out
+
+
+def input_hash(case) -> str:
+    """sha256 over everything the shaders read: the scene arrays, the environment, the frame block, the frame size."""
+    desc = case["scene"][0]
+    h = hashlib.sha256()
+    width = desc.data_texture_width
+    for ptr, count in ((desc.vertex_positions, 3 * width * desc.vertex_data_rows), (desc.vertex_normals, 3 * width * desc.vertex_data_rows),
+                       (desc.group_boxmin, 3 * width * desc.group_data_rows), (desc.group_boxmax, 3 * width * desc.group_data_rows),
+                       (desc.group_objects, 2 * width * desc.group_data_rows), (desc.group_hitmiss, 16 * width * desc.group_data_rows)):
+        h.update(np.ctypeslib.as_array(ptr, shape=(count,)).tobytes())
+    h.update(np.asarray([desc.tree_root, desc.vertex_data_rows, desc.group_data_rows, case["width"], case["height"], case["background_mode"]],
+                        dtype=np.int64).tobytes())
+    h.update(case["env"].tobytes())
+    h.update(bytes(case["params"]))
+    return h.hexdigest()
+
+
+def out_of_tolerance(got: np.ndarray, want: np.ndarray) -> np.ndarray:
+    """Per-pixel mask of helpers.mismatch_mask: any channel further apart than 1e-4 relative (+ 1e-6)."""
+    return helpers.mismatch_mask(got, want)

@@ -235,6 +235,33 @@ def test_environment_storage_float32_and_unorm8(pkg, gpu, oracle_mod, which):
     scene.close()
 
 
+def test_kernels_match_the_reference_shaders(pkg, gpu):
+    """The HIP kernels against frames rendered by the REFERENCE'S OWN GLSL (tests/golden/glsl_reference/*.npz: raytracer.vs +
+    raytracer.es.fs, unmodified, on Mesa's llvmpipe; tests/test_reference_shader.py has the whole story): every case that
+    is asserted for the oracle holds for every kernel, through the C ABI, within the same bounds."""
+    import glsl_cases
+    N = pkg._native
+    checked = 0
+    for name, case in glsl_cases.cases(pkg).items():
+        if case["recorded"]:
+            continue
+        want = np.load(os.path.join(glsl_cases.FIXTURES, name + ".npz"))["frame"]
+        scene = pkg.Scene(case["scene"][0], None, device=0)
+        scene.set_environment(case["env"], N.ENV_UNORM8 if case["env_storage"] else N.ENV_FLOAT32)
+        for kernel in KERNELS:
+            try:
+                scene.set_kernel(kernel)
+            except N.ShrayError:
+                continue            # a chain of leaves is not a binary tree: the literal kernel only
+            got = scene.render(case["params"], case["width"], case["height"], 1)
+            bad = glsl_cases.out_of_tolerance(got, want)
+            rel = (np.abs(got - want)[..., :3] / np.maximum(np.abs(want[..., :3]), 1e-2)).max(axis=-1)
+            assert rel.max() <= case["max_rel"] and bad.sum() <= case["bad_fraction"] * bad.size, (name, kernel, int(bad.sum()), float(rel.max()))
+            checked += 1
+        scene.close()
+    assert checked >= 40
+
+
 def test_empty_world_renders_environment(pkg, gpu, oracle_mod, tmp_path):
     path = tmp_path / "empty.trisrc"
     path.write_text("")

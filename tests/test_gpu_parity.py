@@ -256,7 +256,8 @@ def test_kernels_match_the_reference_shaders(pkg, gpu):
             got = scene.render(case["params"], case["width"], case["height"], 1)
             bad = glsl_cases.out_of_tolerance(got, want)
             rel = (np.abs(got - want)[..., :3] / np.maximum(np.abs(want[..., :3]), 1e-2)).max(axis=-1)
-            assert rel.max() <= case["max_rel"] and bad.sum() <= case["bad_fraction"] * bad.size, (name, kernel, int(bad.sum()), float(rel.max()))
+            assert (rel > case["max_rel"]).sum() <= case["flips"] and bad.sum() <= case["bad_fraction"] * bad.size, \
+                (name, kernel, int(bad.sum()), float(rel.max()))
             checked += 1
         scene.close()
     assert checked >= 40

@@ -177,11 +177,34 @@ def main():
                                        not args.rgba_wire, buffer_sets=lanes)
             me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
         else:
-            ids = [multigpu.unique_id() if rank == 0 else None]
+            failure = None
+            try:
+                ids = [multigpu.unique_id() if rank == 0 else None]
+            except Exception as exc:   # noqa: BLE001
+                ids, failure = [None], repr(exc)
             dist.broadcast_object_list(ids, src=0)
             cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.RCCL, None, tile, tile,
                                        not args.rgba_wire, buffer_sets=lanes)
-            me = multigpu.Rank(scene, cfg, ids[0])      # collective: ncclCommInitRank
+            if ids[0] is not None:
+                try:
+                    me = multigpu.Rank(scene, cfg, ids[0])      # collective: ncclCommInitRank
+                except Exception as exc:   # noqa: BLE001
+                    failure = repr(exc)
+            else:
+                failure = failure or "rank 0 could not make an RCCL id"
+            failures = [None] * world_size
+            dist.all_gather_object(failures, failure)
+            if any(failures):
+                # a communicator that does not come up must not cost the whole measurement: every rank falls back to the
+                # host-staged exchange (slower: the tile buffers cross PCIe twice), and the line says so
+                if rank == 0:
+                    log("RCCL communicator failed on", [k for k, f in enumerate(failures) if f], ":", next(f for f in failures if f))
+                if me is not None:
+                    me.close()
+                transport_name = "gloo, host-staged (RCCL failed: " + next(f for f in failures if f)[:120] + ")"
+                cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.CALLBACK, None, tile, tile,
+                                           not args.rgba_wire, buffer_sets=lanes)
+                me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
     else:
         frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     trials = max(1, args.trials)

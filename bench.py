@@ -11,9 +11,9 @@ region.  Rank 0 prints ONE JSON line.
 
 N = 1: the frame loop hands the C ABI two frames per launch (shray_render_batch_device) and alternates launches
 over four HIP streams.  N > 1 (one process per GPU): every rank drives libshray_dist.so (shray_dist_step): a step of
-the library carries N consecutive frames -- the rank's interleaved tiles of each in one launch, RGB tile buffers
+the library carries 4 N consecutive frames -- the rank's interleaved tiles of each in one launch, RGB tile buffers
 exchanged with grouped ncclSend / ncclRecv over xGMI, frame f of the step de-interleaved on rank f % N (rotating
-roots; --root-mode root0 gathers every frame on rank 0) -- and two such steps alternate on two streams and two buffer
+roots; --root-mode root0 gathers every frame on rank 0) -- and four such steps alternate on four streams and buffer
 sets.  Exactly K frames are rendered in the timed region either way (the last launch is shorter when the frames per
 launch do not divide K).  torch.distributed (gloo) is the control plane only: rendezvous, barrier, max-over-ranks.
 
@@ -106,11 +106,10 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel; --width 3840 --height 2160 --spp 16 is BASELINE configs[4]")
     ap.add_argument("--material", type=int, default=0, help="0 = gold (the headline), 6 = glazed plaster with diffuse white (configs[2])")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent launches alternate over this many HIP streams (1 = strictly one at a time; "
-                         "default: 4 for N = 1, 2 for N > 1)")
+                    help="independent launches alternate over this many HIP streams (1 = strictly one at a time; default: 4)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames per launch (shray_render_batch_device / shray_dist_step).  Default: 2 for "
-                         "N = 1, the number of GPUs for N > 1 (a step then carries one frame's worth of pixels per GPU)")
+                         "N = 1, 4 N for N > 1 (a step then carries four frames' worth of pixels per GPU)")
     ap.add_argument("--root-mode", choices=["rotate", "root0"], default="rotate",
                     help="N > 1: rotate = frame f of a step is assembled on rank f % N (all-to-all over every xGMI link); "
                          "root0 = every frame on rank 0 (gather)")
@@ -163,10 +162,14 @@ def main():
     from shader_ray_amd import multigpu
 
     tile = multigpu.DEFAULT_TILE
-    lanes = max(1, args.frames_in_flight or (2 if distributed else 4))
+    # A GPU wants about eight frames' worth of rays in flight, at least two per launch (profiles/r03/loop_shapes.txt); a
+    # rank of N renders 1 / N of every frame, so its launches carry 4 N frames (its tiles of each) over four streams and
+    # buffer sets (profiles/r03/rank_share_shapes.txt: with N frames per launch on two streams one rank of 8 reached 5.5 x
+    # of one GPU's rate before any exchange, with 4 N on four 7.6 x) -- never more than the K frames there are
+    lanes = max(1, args.frames_in_flight or 4)
     if distributed:
         lanes = min(lanes, 4)      # buffer sets of a shray_dist object
-    batch = max(1, min(64, args.frames_per_launch or (world_size if distributed else 2)))
+    batch = max(1, min(64, args.frames_per_launch or (min(4 * world_size, max(1, args.steps)) if distributed else 2)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = None
     me = None

@@ -53,6 +53,8 @@ struct multi_gpu_job {
     std::vector<double> seconds;      // per rank: the loop's wall time
 };
 
+constexpr int kSets = 4;   // steps in flight per rank
+
 void run_rank(multi_gpu_job *job, int rank)
 {
     auto bail = [&](const char *what, const char *message) {
@@ -74,27 +76,27 @@ void run_rank(multi_gpu_job *job, int rank)
     cfg.width = job->width;
     cfg.height = job->height;
     cfg.spp = job->spp;
-    cfg.max_frames = std::min(job->world, SHRAY_MAX_BATCH);
+    cfg.max_frames = std::min(4 * job->world, SHRAY_MAX_BATCH);   // four frames' worth of rays per launch and rank
     cfg.root_mode = job->root_mode;
     cfg.rgb_wire = 1;
     cfg.transport = job->transport;
-    cfg.buffer_sets = 2;
+    cfg.buffer_sets = kSets;
     const void *arg = job->transport == SHRAY_DIST_LOOPBACK ? (const void *)job->hub : (const void *)job->unique_id;
     if (shray_dist_create(scene, &cfg, arg, &dist) != SHRAY_OK) {
         bail("shray_dist_create", shray_dist_last_error());
         shray_scene_destroy(scene);
         return;
     }
-    hipStream_t streams[2];
+    hipStream_t streams[kSets];
     for (hipStream_t &st : streams)
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
             return bail("hipStreamCreate", "failed");
     const size_t frame_floats = (size_t)job->width * job->height * 4;
     const auto then = std::chrono::steady_clock::now();
-    // two steps in flight on two streams and two buffer sets: the exchange of one runs under the render of the next
+    // kSets steps in flight on as many streams and buffer sets: the exchange of one runs under the render of the next
     int step = 0;
     auto collect = [&](int which_step, int first_frame_of_step, int count) {
-        const int set = which_step % 2;
+        const int set = which_step % kSets;
         int assembled = 0, first = 0, stride = 1;
         void *d_rgba = nullptr;
         if (shray_dist_output(dist, set, count, &assembled, &first, &stride, &d_rgba) != SHRAY_OK)
@@ -110,9 +112,9 @@ void run_rank(multi_gpu_job *job, int rank)
     int pending_first = -1, pending_count = 0;
     for (int f0 = 0; f0 < job->frames; f0 += cfg.max_frames, step++) {
         const int count = std::min(cfg.max_frames, job->frames - f0);
-        if (step >= 2)
-            (void)hipStreamSynchronize(streams[step % 2]);   // the readbacks of the step that used this buffer set
-        if (shray_dist_step(dist, step % 2, job->params->data() + f0, count, streams[step % 2]) != SHRAY_OK) {
+        if (step >= kSets)
+            (void)hipStreamSynchronize(streams[step % kSets]);   // the readbacks of the step that used this buffer set
+        if (shray_dist_step(dist, step % kSets, job->params->data() + f0, count, streams[step % kSets]) != SHRAY_OK) {
             bail("shray_dist_step", shray_dist_last_error());
             break;
         }

@@ -9,7 +9,7 @@ through the real parser + BVH builder), seeded HDR sky environment, 1920x1080, 1
 ray.cpp:879-918: ORBIT distinct views, replayed): scene and environment are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-N = 1: the frame loop hands the C ABI two frames per launch (shray_render_batch_device) and alternates launches
+N = 1: the frame loop hands the C ABI four frames per launch (shray_render_batch_device) and alternates launches
 over four HIP streams.  N > 1 (one process per GPU): every rank drives libshray_dist.so (shray_dist_step): a step of
 the library carries 4 N consecutive frames -- the rank's interleaved tiles of each in one launch, RGB tile buffers
 exchanged with grouped ncclSend / ncclRecv over xGMI, frame f of the step de-interleaved on rank f % N (rotating
@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent launches alternate over this many HIP streams (1 = strictly one at a time; default: 4)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="consecutive frames per launch (shray_render_batch_device / shray_dist_step).  Default: 2 for "
+                    help="consecutive frames per launch (shray_render_batch_device / shray_dist_step).  Default: 4 for "
                          "N = 1, 4 N for N > 1 (a step then carries four frames' worth of pixels per GPU)")
     ap.add_argument("--root-mode", choices=["rotate", "root0"], default="rotate",
                     help="N > 1: rotate = frame f of a step is assembled on rank f % N (all-to-all over every xGMI link); "
@@ -169,7 +169,7 @@ def main():
     lanes = max(1, args.frames_in_flight or 4)
     if distributed:
         lanes = min(lanes, 4)      # buffer sets of a shray_dist object
-    batch = max(1, min(64, args.frames_per_launch or (min(4 * world_size, max(1, args.steps)) if distributed else 2)))
+    batch = max(1, min(64, args.frames_per_launch or (min(4 * world_size, max(1, args.steps)) if distributed else 4)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = None
     me = None

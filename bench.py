@@ -321,7 +321,7 @@ def main():
                                    + ("gold" if args.material == 0 else f"material {args.material}") + ", 3 bounces"
                                    + (" (BASELINE configs[1])" if headline else "")
                                    + (f"; the frames are a trackball orbit of {ORBIT} views, replayed" if not args.same_view else "; one view"),
-                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "pool", 3: "stack, pair turns"}[args.kernel],
+                       "width": WIDTH, "height": HEIGHT, "spp": SPP, "kernel": {0: "stack", 1: "threaded", 2: "pool", 3: "stack, pair turns", 4: "wavefront"}[args.kernel],
                        "parallelism": (f"tiles{tile}x{tile}-interleaved-x{world_size}, libshray_dist ({transport_name}), "
                                        f"{'rotating roots (all-to-all)' if args.root_mode == 'rotate' else 'gather to rank 0'}")
                        if distributed else "single-gpu",

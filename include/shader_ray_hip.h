@@ -229,7 +229,8 @@ int shray_scene_device(const shray_scene *scene, int *device_index);
 /* Kernel selection: 0 = per-ray LDS stack kernel (default), 1 = literal threaded hit/miss-table traversal
  * over the reference arrays, 2 = pool kernel (a workgroup's waves merge their live rays while they
  * traverse: for divergent scenes), 3 = the stack kernel with both children of a node tested per turn in every
- * launch that can (kernel 0 chooses that form itself where it pays).  All of them produce bit-identical frames and,
+ * launch that can, 4 = the wavefront form (one launch per bounce, the live paths compacted in between; whole frames
+ * of the plain view, everything else runs kernel 0's instances).  All of them produce bit-identical frames and,
  * through shray_render_counters, the same work counters. */
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id);
 

@@ -123,6 +123,13 @@ struct shray_scene {
     bool batch_pending[kBatchSlots] = {};
     int batch_next = 0;
 
+    // kernel id 4 (wavefront form): path queues, counts and per-sample radiances, grown on demand; one launch of a
+    // scene at a time uses them (launches on different streams are ordered by wf_done)
+    DeviceBuffer wf_queue0, wf_queue1, wf_counts, wf_radiance;
+    size_t wf_paths = 0;
+    hipEvent_t wf_done = nullptr;
+    bool wf_pending = false;
+
     // shray_render / shray_render_host_async: the device frame is kept between calls (grown on demand),
     // and the blocking form's readback runs on the scene's own stream
     DeviceBuffer frame;
@@ -135,6 +142,8 @@ struct shray_scene {
     {
         if (readback_stream)
             (void)hipStreamDestroy(readback_stream);
+        if (wf_done)
+            (void)hipEventDestroy(wf_done);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -498,6 +507,39 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
     bool plain_view = true;   // the pool kernel renders which == 0 frames; the shader's debug views stay on the stack kernel
     for (int k = 0; k < count; k++)
         plain_view = plain_view && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
+    if (scene->kernel_id == 4 && plain_view && !tally && count == 1 && views[0].tile_stride == 0) {
+        // the wavefront form: one launch per bounce over queues of live paths
+        const FrameView &fr = views[0];
+        const size_t paths = (size_t)fr.width * fr.height * fr.spp;
+        if (scene->wf_paths < paths) {
+            HIP_TRY(hipDeviceSynchronize());     // nothing may still be using the old queues
+            scene->wf_queue0.release();
+            scene->wf_queue1.release();
+            scene->wf_radiance.release();
+            scene->wf_paths = 0;
+            HIP_TRY(hipMalloc(&scene->wf_queue0.p, paths * 64));
+            HIP_TRY(hipMalloc(&scene->wf_queue1.p, paths * 64));
+            HIP_TRY(hipMalloc(&scene->wf_radiance.p, paths * 16));
+            scene->wf_paths = paths;
+        }
+        if (!scene->wf_counts.p)
+            HIP_TRY(scene->wf_counts.upload(nullptr, sizeof(unsigned int) * 80));
+        if (!scene->wf_done)
+            HIP_TRY(hipEventCreateWithFlags(&scene->wf_done, hipEventDisableTiming));
+        if (fr.bounce_count + 2 > 80)
+            return fail(SHRAY_ERR_INVALID_ARGUMENT, "bounce_count %d is too large for the wavefront kernel", fr.bounce_count);
+        if (scene->wf_pending)
+            HIP_TRY(hipStreamWaitEvent(stream, scene->wf_done, 0));
+        const hipError_t we = launch_wavefront(scene->view, d_views, fr, all_metal, (PathState *)scene->wf_queue0.p, (PathState *)scene->wf_queue1.p,
+                                               (unsigned int *)scene->wf_counts.p, (float4 *)scene->wf_radiance.p, d_out, stream, scene->stack_levels);
+        if (we != hipSuccess)
+            return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(we));
+        HIP_TRY(hipEventRecord(scene->wf_done, stream));
+        scene->wf_pending = true;
+        HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
+        scene->batch_pending[slot] = true;
+        return SHRAY_OK;
+    }
     const hipError_t e = (scene->kernel_id == 2 && plain_view && !tally)
         ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
         : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
@@ -812,8 +854,9 @@ int shray_scene_device(const shray_scene *scene, int *device_index)
 
 int shray_scene_set_kernel(shray_scene *scene, int kernel_id)
 {
-    if (!scene || kernel_id < 0 || kernel_id > 3)
-        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = pool, 3 = stack with pair turns)", kernel_id);
+    if (!scene || kernel_id < 0 || kernel_id > 4)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "kernel id %d (0 = stack, 1 = threaded, 2 = pool, 3 = stack with pair turns, 4 = wavefront)",
+                    kernel_id);
     if (kernel_id != 1 && !scene->packed_ok)
         return fail(SHRAY_ERR_BAD_TREE, "the scene's hit/miss tables are not a canonical threaded tree; only the "
                     "literal threaded kernel (1) can run it");
@@ -889,7 +932,7 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     char *out = (char *)d_rgba_out;
 
     // anything but the stack kernel runs as plain consecutive launches
-    if (scene->kernel_id == 1 || !scene->packed_ok || scene->patch_order.p) {
+    if (scene->kernel_id == 1 || scene->kernel_id == 4 || !scene->packed_ok || scene->patch_order.p) {
         for (int k = 0; k < count; k++) {
             const int rc = launch(scene, views[k], (float4 *)(out + (size_t)k * frame_stride_bytes), nullptr, stream);
             if (rc)
@@ -1087,7 +1130,7 @@ int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *pa
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "frames_per_launch %d (1..%d)", frames_per_launch, SHRAY_MAX_BATCH);
     const bool view = params->which == 1 || params->which == 2 || params->which == 3 || params->which == 5;
     // only the stack kernel's convergent instances have a timed form of their own; everything else is timed as it counts
-    if ((scene->kernel_id != 0 && scene->kernel_id != 3) || !scene->packed_ok || view || scene->patch_order.p)
+    if ((scene->kernel_id != 0 && scene->kernel_id != 3 && scene->kernel_id != 4) || !scene->packed_ok || view || scene->patch_order.p)
         return shray_render_counters(scene, params, width, height, spp, rgba_out_host, counters);
     if (!scene->view.env)
         return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");

@@ -38,6 +38,13 @@ hipError_t launch_pool(const SceneView &sc, const FrameView &fr, float4 *out, De
 hipError_t launch_pool_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                              float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels);
 
+// kernel id 4 (kernel_wavefront.hip): trace() split by bounce, one launch per bounce with the live paths compacted in
+// between; whole plain frames only.  d_view: the frame's view in device memory; queue0 / queue1: width * height * spp
+// path records of 64 bytes each; counts: bounce_count + 2 words; radiance: width * height * spp float4 (spp > 1 only)
+struct PathState;
+hipError_t launch_wavefront(const SceneView &sc, const FrameView *d_view, const FrameView &fr, bool metal, PathState *queue0, PathState *queue1,
+                            unsigned int *counts, float4 *radiance, float4 *out, hipStream_t stream, int stack_levels);
+
 // rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,
 // frame_stride between a rank's consecutive frames
 // (c0, c1): phases per period owned by rank 0 / by every other rank (1, 1 = even split)

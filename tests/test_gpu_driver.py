@@ -133,7 +133,7 @@ def test_config4_full_size_million_triangles_4spp(pkg, gpu, oracle_mod):
     # the cap is 'a little too few' for this tree: a few samples per 100,000 hit it
     fraction = cpu["bad_hits"] / cpu["samples"]
     assert 0 < fraction < 1e-3, fraction
-    for kernel in (0, 1, 3):     # 3: both children per turn; its counting twin reproduces the capped samples' tallies too
+    for kernel in (0, 1, 3, 4):  # 3: both children per turn (its counting twin reproduces the capped samples' tallies too); 4: wavefront form
         scene.set_kernel(kernel)
         got, counters = scene.render_counters(params, W, H, spp)
         assert_images_match(got, want, f"config 4 kernel {kernel}")
@@ -206,7 +206,7 @@ def test_shader_constants_as_parameters(pkg, gpu, oracle_mod, material):
             for key, value in overrides.items():
                 setattr(params, key, value)
             want, cpu = oracle_mod.render(desc, env, params, W, H, spp)
-            for kernel in (0, 1, 2, 3):
+            for kernel in (0, 1, 2, 3, 4):
                 scene.set_kernel(kernel)
                 got, counters = scene.render_counters(params, W, H, spp)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (overrides, spp, kernel)

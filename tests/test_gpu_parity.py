@@ -18,8 +18,9 @@ from helpers import assert_images_match, default_params, single_leaf_scene
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # 0 = packed stack kernel, 1 = literal threaded kernel, 2 = pool kernel (waves merge mid-traversal),
-# 3 = stack kernel with both children of a node per turn (its counters come from its own counting twin)
-KERNELS = [0, 1, 2, 3]
+# 3 = stack kernel with both children of a node per turn (its counters come from its own counting twin),
+# 4 = wavefront form: one launch per bounce, live paths compacted in between (counters: kernel 0's counting twin)
+KERNELS = [0, 1, 2, 3, 4]
 
 
 @pytest.fixture(scope="module")
@@ -625,7 +626,7 @@ env = pkg.scenes.environment_hdr_sky(64)
 params = world.frame_params(96, 72, material=6)
 want, cpu = oracle.render(desc, env, params, 96, 72, 1)
 scene = pkg.Scene(desc, env, device=0)
-for kernel in (0, 1, 2, 3):
+for kernel in (0, 1, 2, 3, 4):
     scene.set_kernel(kernel)
     got, gpu = scene.render_counters(params, 96, 72, 1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), kernel

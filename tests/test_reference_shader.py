@@ -127,4 +127,5 @@ def test_live_reference_shader_reproduces_a_fixture(all_cases, oracle_mod):
     frame, log = oracle_mod.render_reference_shader(case["scene"][0], case["env"], case["params"], case["width"], case["height"],
                                                     case["background_mode"], case["anisotropy"])
     assert "llvmpipe" in log
-    assert np.array_equal(frame, load_fixture("lobed_plaster_constant_rotated")["frame"])
+    # (llvmpipe compiles the shaders for the host's vector width: allow the last bits to differ between machines)
+    assert agreement(frame, load_fixture("lobed_plaster_constant_rotated")["frame"])[3] < 1e-5

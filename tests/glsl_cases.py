@@ -29,14 +29,21 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 FIXTURES = os.path.join(GOLDEN, "glsl_reference")
 
 
-def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, **more):
+def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, drags=(), move=None, zoom=None, diffuse=None, **more):
     world = pkg.World(path)
     view = world.default_view()
     view.which = which
     for _ in range(rotate):
         pkg.host.trackball_motion(view.object_rotation, 0.11, -0.07)
         pkg.host.trackball_motion(view.light_rotation, -0.05, 0.09)
-    params = world.frame_params(width, height, view, material=material)
+    for dx, dy, lx, ly in drags:          # mouse drags of the object and of the light (ray.cpp:879-918)
+        pkg.host.trackball_motion(view.object_rotation, dx, dy)
+        pkg.host.trackball_motion(view.light_rotation, lx, ly)
+    if move is not None:
+        view.object_position[:] = move
+    if zoom is not None:
+        view.zoom = view.zoom * zoom
+    params = world.frame_params(width, height, view, material=material, diffuse=diffuse)
     return dict(scene=(world.flatten(), world), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=width,
                 height=height, background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, flips=0, recorded=False, why="",
                 **more)
@@ -95,6 +102,22 @@ def cases(pkg):
     out["million_gold_constant_192"].update(max_rel=1e-2, bad_fraction=0.08, flips=210,
                                             why="three mirror bounces off a 1M-facet bumpy sphere amplify the compiler's last-bit differences: "
                                                 "median 2e-7, 94.5 % of the pixels within 1e-4, 0.5 % beyond 1e-2; the capped pixel is the same pixel")
+    # -- every material of the reference's table (ray.cpp:54-65) and every diffuse colour (:68-73), an object moved off the
+    #    origin, a closer camera: the uniforms of ray.cpp:648-704 one by one
+    for material in range(7):
+        out[f"lobed_material{material}_constant"] = _world_case(pkg, lobed, constant, 48, 32, material, rotate=material % 3)
+    for diffuse in range(1, 4):
+        out[f"lobed_plaster_diffuse{diffuse}_constant"] = _world_case(pkg, lobed, constant, 48, 32, 6, diffuse=diffuse)
+    out["lobed_chrome_moved_constant"] = _world_case(pkg, lobed, constant, 64, 48, 1, move=(0.3, -0.2, 0.5), rotate=1)
+    out["lobed_plaster_close_sky_isotropic"] = _world_case(pkg, lobed, sky, 64, 48, 6, zoom=0.6)
+    out["lobed_plaster_close_sky_isotropic"]["anisotropy"] = 1.0
+    # -- ten seeded random views (object and light dragged at random), gold and plaster alternating
+    rng = np.random.default_rng(20261004)
+    for k in range(10):
+        drags = [tuple(float(v) for v in rng.uniform(-0.4, 0.4, 4)) for _ in range(3)]
+        c = _world_case(pkg, lobed, sky if k % 2 else constant, 64, 48, (0, 6)[k % 2], drags=drags, zoom=float(rng.uniform(0.7, 1.3)))
+        c.update(anisotropy=1.0, flips=2)
+        out[f"lobed_random_view_{k}"] = c
     # -- the analytic known-answer scenes of test_oracle_kat.py, through the real shader
     out["kat_env_only"] = _hand_case(pkg, kat.far_away_triangle(), sky, default_params(pkg, 48, 32), 48, 32, )
     out["kat_env_only"]["anisotropy"] = 1.0

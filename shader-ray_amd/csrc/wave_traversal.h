@@ -38,6 +38,23 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 #ifndef SHRAY_LDS_TOP
 #define SHRAY_LDS_TOP 0
 #endif
+// round 3: the stack position moved by an add tied to its register (top_move), the leaf's count word parked as it is
+// and clamped once per leaf stage (parked_count): five vector instructions fewer per node turn in the ISA
+#ifndef SHRAY_TIED_TOP
+#define SHRAY_TIED_TOP 1
+#endif
+#ifndef SHRAY_TRIANGLE_WORDS
+#define SHRAY_TRIANGLE_WORDS 1
+#endif
+#ifndef SHRAY_TIED_ACCEPT
+#define SHRAY_TIED_ACCEPT 1
+#endif
+#ifndef SHRAY_BUFFER_LOADS
+#define SHRAY_BUFFER_LOADS 0
+#endif
+#ifndef SHRAY_PARK_RAW
+#define SHRAY_PARK_RAW 1
+#endif
 // node visits per lane between two evaluations of inner_stage's exit tests (fewer instructions against more
 // registers; three measured best in round 2, profiles/r02/leaf_stage_ab.txt)
 #ifndef SHRAY_NODE_TURNS
@@ -80,6 +97,22 @@ struct LaneTraversal {
 
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// The stack position moves by one slot.  Written as a plain `top += BLOCK` in one branch of the visit it becomes a
+// loop-carried phi that the compiler resolves with a register copy on each of the OTHER branches and one more where
+// they meet (three moves per node turn in the ISA); an add tied to its own register keeps it in place on every path.
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+template <int BYTES>
+__device__ __forceinline__ void top_move(uint32_t *&top)
+{
+#if SHRAY_TIED_TOP
+    lds_word *p = (lds_word *)top;
+    asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(p) : "i"((unsigned int)BYTES));
+    top = (uint32_t *)p;
+#else
+    top += BYTES / 4;
+#endif
+}
+
 // group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
 template <bool COUNT>
 __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack, V3 P, V3 D,
@@ -115,7 +148,7 @@ __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, b
     } else if (t.top == stack) {
         return LT_ENDED;        // finished: `left` is not counted down (the cap does not apply to a finished ray)
     } else {
-        t.top -= BLOCK;
+        top_move<-4 * BLOCK>(t.top);
         t.node = *t.top;
     }
     t.left--;
@@ -143,9 +176,19 @@ __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
 // triangle byte offsets stay far below 2^32.)
 __device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
 {
+#if SHRAY_BUFFER_LOADS
+    // experiment: the same two loads as MUBUF instructions (a buffer descriptor in four scalar registers + the offset)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(static_cast<const void *>(sc.packed_nodes)), 0, -1, 0x00020000);
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(node << 5), 0, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(node << 5) + 16, 0, 0);
+    lo = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    hi = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+#else
     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + (node << 5));
     lo = p[0];
     hi = p[1];
+#endif
 }
 
 // range_intersect_box of the node's box against [0, 1e8] (fs:200-217, :272-275): the entry plane is the box's low
@@ -185,8 +228,15 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
 
     if (!(r0 >= r1) && (r0 < t.hit.t)) {
         if (b & kLeafFlag) {
+#if SHRAY_PARK_RAW
+            // the leaf's count word is parked as it is (flag bit and all); the leaf stages clamp it to the leaf cap
+            // once per stage (parked_count) instead of every visit masking, clamping and testing it
+            const uint32_t count = b;
+            if (b != kLeafFlag && t.leaf_cap != 0u) {
+#else
             const uint32_t count = min(b & ~kLeafFlag, t.leaf_cap);
             if (count > 0) {
+#endif
                 // the parked leaf's four fields are written HERE only.  As plain assignments they become loop-carried
                 // phis that the compiler resolves with eight register copies on the inner-node path (the common one);
                 // a move whose destination is tied to the old value keeps each field in one register on every path.
@@ -201,7 +251,7 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
         const uint32_t pos_child = a & kChildMask, neg_child = b;
         const bool neg_first = (t.positive_dir >> axis) & 1u;
         *t.top = neg_first ? pos_child : neg_child;
-        t.top += BLOCK;
+        top_move<4 * BLOCK>(t.top);
         return lane_advance<BLOCK>(t, stack, true, neg_first ? neg_child : pos_child);
     }
     return lane_advance<BLOCK>(t, stack, false, 0u);
@@ -235,7 +285,16 @@ __device__ __forceinline__ bool triangle_distance(const LaneTraversal &t, const 
     s.T = t.P - v0;
     s.Q = cross3(s.T, e0);
     s.dist = -dot3(e1, s.Q) * s.inv_det;
+#if SHRAY_TRIANGLE_WORDS
+    // `d > hit.t || d > r1` is `d > min(hit.t, r1)` whatever is NaN (the hardware minimum returns the other operand, and a
+    // comparison with NaN is false either way); the compiler makes the same fold but canonicalises both operands first
+    // (two v_max x, x per test).  One bare v_min_f32:
+    float upper;
+    asm("v_min_f32 %0, %1, %2" : "=v"(upper) : "v"(t.hit.t), "v"(t.leaf_r1));
+    return !(s.dist > upper || s.dist < t.leaf_r0);
+#else
     return !(s.dist > t.hit.t || s.dist < t.leaf_r0 || s.dist > t.leaf_r1);
+#endif
 }
 // Second half, fs:333-346: the barycentric tests and the store.
 __device__ __forceinline__ void triangle_barycentrics(LaneTraversal &t, uint32_t which, const TriangleSetup &s)
@@ -274,6 +333,29 @@ struct PackedF3 {
 __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
 {
     // base + 32-bit byte offset, as for the nodes
+#if SHRAY_BUFFER_LOADS
+    typedef unsigned int v3u __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(static_cast<const void *>(sc.packed_tris)), 0, -1, 0x00020000);
+    const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u), 0, 0);
+    const v3u b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u) + 12, 0, 0);
+    const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u) + 24, 0, 0);
+    q0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(b.x));
+    q1 = make_float4(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(c.x), __uint_as_float(c.y));
+    q2 = make_float4(__uint_as_float(c.z), 0.0f, 0.0f, 0.0f);
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x));
+#elif SHRAY_TRIANGLE_WORDS
+    // 36 bytes as 16 + 16 + 4 (what the back end makes of three 12-byte loads anyway), pinned as the register tuples the
+    // loads fill: pinned component by component, every test began with five or six moves out of those tuples
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef f4 __attribute__((aligned(4), may_alias)) packed_f4;
+    const char *p = reinterpret_cast<const char *>(sc.packed_tris) + index * 36u;
+    f4 a = *reinterpret_cast<const packed_f4 *>(p), b = *reinterpret_cast<const packed_f4 *>(p + 16);
+    float c = *reinterpret_cast<const float *>(p + 32);
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+    q0 = make_float4(a.x, a.y, a.z, a.w);
+    q1 = make_float4(b.x, b.y, b.z, b.w);
+    q2 = make_float4(c, 0.0f, 0.0f, 0.0f);
+#else
     const PackedF3 *p = reinterpret_cast<const PackedF3 *>(reinterpret_cast<const char *>(sc.packed_tris) + index * 36u);
     const PackedF3 a = p[0], b = p[1], c = p[2];
     q0 = make_float4(a.x, a.y, a.z, b.x);
@@ -281,6 +363,7 @@ __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32
     q2 = make_float4(c.z, 0.0f, 0.0f, 0.0f);
     // pin the nine components here: whole loads, nothing deferred past a branch
     asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x));
+#endif
 }
 
 template <bool COUNT>
@@ -336,33 +419,50 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_pop(const SceneView &sc, LaneTraversal &t, uint32_t *stack, RayCounters &rc);
 
+// triangles a parked lane tests: its leaf's count (the flag bit may still be on it), at most max_leaf_tests (fs:411)
+__device__ __forceinline__ uint32_t parked_count(uint32_t leaf_count, uint32_t leaf_cap) { return min(leaf_count & ~kLeafFlag, leaf_cap); }
+
 // Leaf stage: every parked lane tests its leaf's triangles in order, then follows its link.
 // PAIR: the lane belongs to the pair traversal (below): "follow the link" is lane_pop.
-template <bool COUNT, int BLOCK, bool PAIR = false>
-__device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                           uint32_t *stack, RayCounters &rc SHRAY_DIAG_PARAM)
+// its loop (some lane must be parked) ...
+template <bool COUNT>
+__device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
 {
-    if (!wave_ballot(state == LT_LEAF))
-        return;
 #ifdef SHRAY_DIAGNOSTICS
     {   // how much a triangle-parallel leaf stage could save: stages, and 64-wide rounds over all parked triangles
-        unsigned int total = (state == LT_LEAF) ? t.leaf_count : 0u;
+        unsigned int total = (state == LT_LEAF) ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
         for (int off = 32; off > 0; off >>= 1)
             total += __shfl_xor(total, off, 64);
         diag_tally_ref[6] += 1;
         diag_tally_ref[7] += (total + 63u) / 64u;
     }
 #endif
-    for (uint32_t j = 0; wave_ballot(state == LT_LEAF && j < t.leaf_count); j++) {
+    // a lane that is not parked has no triangles: ONE comparison per round decides both who works and whether anyone does
+    // (as `state == LT_LEAF && j < count` the wave-level test cost a select and a second comparison per round; the pin
+    // keeps the compiler from turning it back into that)
+    uint32_t mine = state == LT_LEAF ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
+    asm volatile("" : "+v"(mine));
+    // bottom-tested: some lane is parked, and a parked lane has at least one triangle (a top-tested loop over a wave-level
+    // condition is not rotated by the compiler, and then carries the hit's four fields in two register sets with a copy at
+    // every level of the test's early-outs)
+    uint32_t j = 0;
+    do {
         SHRAY_DIAG_COUNT(1);
-        if (state == LT_LEAF && j < t.leaf_count) {
+        if (j < mine) {
             float4 q0, q1, q2;
             SHRAY_DIAG_T0
             load_packed_triangle(sc, t.leaf_first + j, q0, q1, q2);
             SHRAY_DIAG_WAIT(5);
             lane_test_triangle_loaded<COUNT>(t, t.leaf_first + j, rc, q0, q1, q2);
         }
-    }
+        j++;
+    } while (wave_ballot(j < mine));
+}
+
+// ... and its end: the parked lanes move on (fs:416-433)
+template <bool COUNT, int BLOCK, bool PAIR>
+__device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &t, int &state, uint32_t *stack, RayCounters &rc)
+{
     if (PAIR) {
         if (state == LT_LEAF)
             state = lane_pop<COUNT, BLOCK>(sc, t, stack, rc);
@@ -371,6 +471,16 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, false, 0u);
     lane_apply_cap(t, state);
+}
+
+template <bool COUNT, int BLOCK, bool PAIR = false>
+__device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                           uint32_t *stack, RayCounters &rc SHRAY_DIAG_PARAM)
+{
+    if (!wave_ballot(state == LT_LEAF))
+        return;
+    leaf_loop<COUNT>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+    leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -435,19 +545,15 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
     return true;
 }
 
-// `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its lane number)
-template <bool COUNT, int BLOCK, bool PAIR = false>
-__device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                                 uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
+// The search of a dealt stage: `parked` = the lanes in LT_LEAF (K of them, K <= SHRAY_DEAL_MAX_PARKED).  Returns true if
+// a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
+// (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its
+// lane number)
+template <bool COUNT>
+__device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTraversal &t, int state, RayCounters &rc, uint8_t *ids,
+                                             unsigned long long parked, int K, float &wd, float &wu, float &ww,
+                                             uint32_t &won SHRAY_DIAG_PARAM)
 {
-    const unsigned long long parked = wave_ballot(state == LT_LEAF);
-    if (!parked)
-        return;
-    const int K = __popcll(parked);
-    if (K > SHRAY_DEAL_MAX_PARKED) {
-        leaf_stage<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG_FWD);
-        return;
-    }
     const int log_g = K <= 4 ? 4 : (K <= 8 ? 3 : (K <= 16 ? 2 : 1));   // G = 16, 8, 4, 2
     const int G = 1 << log_g;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -465,13 +571,17 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     const uint32_t first = (uint32_t)lane_pull(src, (int)t.leaf_first);
     // (every pull is a statement of its own, executed by all 64 lanes: ds_bpermute returns 0 for a source lane that
     // is masked off, so a pull must never sit inside a conditional expression)
-    const uint32_t count = (uint32_t)lane_pull(src, (int)t.leaf_count);
-    const uint32_t end = worker ? first + count : 0u;
+    const uint32_t count = parked_count((uint32_t)lane_pull(src, (int)t.leaf_count), t.leaf_cap);
+    uint32_t end = worker ? first + count : 0u;
+    asm volatile("" : "+v"(end));   // one comparison per round (see leaf_stage)
     float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
     uint32_t best = 0xffffffffu;    // no candidate accepted
     bool unordered = false;         // accepted a candidate whose d is NaN (see above)
+    uint32_t unordered_flag = 0u;   // the same, kept in a vector register by the tied form below
     SHRAY_DIAG_COUNT(6);
-    for (uint32_t tri = first + (uint32_t)sub; wave_ballot(tri < end); tri += (uint32_t)G) {
+    // bottom-tested, like leaf_stage's loop: group 0's first worker always has a triangle
+    uint32_t tri = first + (uint32_t)sub;
+    do {
         SHRAY_DIAG_COUNT(1);
         if (tri < end) {
             float4 q0, q1, q2;
@@ -480,19 +590,29 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
                 rc.triangle_tests++;
             float d, u, w;
             if (triangle_candidate(P, D, r0, r1, q0, q1, q2, d, u, w) && !(d > best_d)) {
+#if SHRAY_TIED_ACCEPT
+                // the worker's best candidate so far is rewritten HERE only, deep inside the test's early-outs: as plain
+                // assignments the four values (and the flag, a lane mask) are copied back and forth at every level of that
+                // nest, ~24 moves and a dozen scalar mask operations per triangle; tied to their registers, none
+                asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\t"
+                             "v_cmp_u_f32 vcc, %5, %5\n\tv_cndmask_b32 %4, %4, 1, vcc"
+                             : "+v"(best_d), "+v"(best_u), "+v"(best_w), "+v"(best), "+v"(unordered_flag)
+                             : "v"(d), "v"(u), "v"(w), "v"(tri)
+                             : "vcc");
+#else
                 best_d = d;
                 best_u = u;
                 best_w = w;
                 best = tri;
                 unordered = unordered || d != d;
+#endif
             }
         }
-    }
-    if (__builtin_expect(wave_ballot(unordered) != 0ull, 0)) {
+        tri += (uint32_t)G;
+    } while (wave_ballot(tri < end));
+    if (__builtin_expect(wave_ballot(unordered || unordered_flag != 0u) != 0ull, 0)) {
         asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
-        // the parked rays have not been touched yet; the triangle tests were tallied above
-        leaf_stage<false, BLOCK, PAIR>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG_FWD);
-        return;
+        return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
     }
     // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
     for (int step = 1; step < G; step <<= 1) {
@@ -508,19 +628,44 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     }
     // the parked lane collects its group's winner and moves on (fs:416-433)
     const int from = rank << log_g;
-    const float wd = lane_pull(from, best_d), wu = lane_pull(from, best_u), ww = lane_pull(from, best_w);
-    const uint32_t won = (uint32_t)lane_pull(from, (int)best);
-    if (state == LT_LEAF) {
-        if (won != 0xffffffffu) {
-            t.hit.which = (float)won;
-            t.hit.t = wd;
-            t.hit.bu = wu;
-            t.hit.bv = ww;
-        }
-        state = PAIR ? lane_pop<COUNT, BLOCK>(sc, t, stack, rc) : lane_advance<BLOCK>(t, stack, false, 0u);
+    wd = lane_pull(from, best_d);
+    wu = lane_pull(from, best_u);
+    ww = lane_pull(from, best_w);
+    won = (uint32_t)lane_pull(from, (int)best);
+    return false;
+}
+
+// One call site of the plain loop serves both the crowded stage (more than SHRAY_DEAL_MAX_PARKED lanes parked) and the
+// unordered fallback in the timed instances, and one end (leaf_finish) serves every path: each inlined copy is another
+// 150 instructions and another set of register copies where its results meet the other paths'.
+template <bool COUNT, int BLOCK, bool PAIR = false>
+__device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
+                                                 uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
+{
+    const unsigned long long parked = wave_ballot(state == LT_LEAF);
+    if (!parked)
+        return;
+    const int K = __popcll(parked);
+    float wd = 0.0f, wu = 0.0f, ww = 0.0f;
+    uint32_t won = 0xffffffffu;
+    bool plain = K > SHRAY_DEAL_MAX_PARKED, tallied = false;
+    if (!plain) {
+        plain = dealt_search<COUNT>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
+        tallied = true;
     }
-    if (!PAIR)
-        lane_apply_cap(t, state);
+    if (plain) {
+        if (COUNT && !tallied)
+            leaf_loop<COUNT>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+        else
+            leaf_loop<false>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+    } else if (state == LT_LEAF && won != 0xffffffffu) {
+        // the parked lane takes its group's winner
+        t.hit.which = (float)won;
+        t.hit.t = wd;
+        t.hit.bu = wu;
+        t.hit.bv = ww;
+    }
+    leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
 }
 
 // ---------------------------------------------------------------------------------------------------

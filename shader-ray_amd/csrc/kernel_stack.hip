@@ -126,6 +126,8 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR>;
     Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR>(lds_stack, stack_levels, sc);
+    if (ONE_SAMPLE)
+        trav.keep_dealt = SHRAY_KEEP_WALKING_DEALT_ONE;
 #if SHRAY_WAVE_BLOCKS == 2 && SHRAY_INTERLEAVE_FRAMES
     // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
     // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
@@ -153,6 +155,23 @@ __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE
                                                                                                int frame_count_arg)
 {
     stack_batch_body<ONE_SAMPLE, METAL, DEAL, 0, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+}
+
+// Several spp == 1 zero-diffuse frames per launch (the throughput form): the dealt leaf stage at SEVEN waves per SIMD
+// (72 registers, 24 B of scratch).  Round 2 gave these launches the plain leaf loop for its eighth wave; since the dealt
+// loop lost its register copies (round 3, wave_traversal.h) seven dealing waves beat eight plain ones by 2.7 %, while a
+// lone frame still does best with six (no scratch): profiles/r03/dealt_occupancy_ab2.txt.
+#ifndef SHRAY_THROUGHPUT_DEALT
+#define SHRAY_THROUGHPUT_DEALT 1
+#endif
+#ifndef SHRAY_MIN_WAVES_DEALT_DENSE
+#define SHRAY_MIN_WAVES_DEALT_DENSE 7
+#endif
+__global__ void __launch_bounds__(kBatchBlock, SHRAY_MIN_WAVES_DEALT_DENSE)
+    trace_stack_batch_dense_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride, int stack_levels,
+                                   int frame_count_arg)
+{
+    stack_batch_body<true, true, true, 0, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
 }
 
 // The pair traversal (dealt leaf stage): for launches that are bound by dependent round trips -- a lone frame, a tree
@@ -249,8 +268,10 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
         return hipGetLastError();
     }
 #undef SHRAY_LAUNCH_PAIR_TALLY
+    // the throughput form of the headline workload deals its leaves too, at its own occupancy (trace_stack_batch_dense_kernel)
+    const bool dense = SHRAY_THROUGHPUT_DEALT && one && metallic && !deal && !pair && all_plain;
     if (tally && all_plain) {   // the same choice of instance as below, with tallies
-        if (one && metallic && deal)
+        if (one && metallic && (deal || dense))
             SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, true, true>));
         else if (one && metallic)
             SHRAY_LAUNCH_TALLY((trace_stack_batch_tally_kernel<true, true, false>));
@@ -285,6 +306,8 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     else if (pair)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<false, false>));
     // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of each class of instances
+    else if (dense)
+        SHRAY_LAUNCH_BATCH(trace_stack_batch_dense_kernel);
     else if (one && metallic && deal)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_kernel<true, true, true>));
     else if (one && metallic)

@@ -32,6 +32,12 @@ constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
 #define SHRAY_KEEP_WALKING_DEALT 48
 #endif
 constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
+// ... and with one ray per pixel it yields as soon as ANY lane is parked (64 of 64: measured 48 ... 64 on the orbit
+// workload, profiles/r03/dealt_keep_walking_ab.txt: +1.3 % throughput at 64, a lone frame no slower); the multi-sample
+// instances (sample lanes: more coherent waves) keep 48
+#ifndef SHRAY_KEEP_WALKING_DEALT_ONE
+#define SHRAY_KEEP_WALKING_DEALT_ONE 64
+#endif
 #ifndef SHRAY_RELATIVE_KEEP
 #define SHRAY_RELATIVE_KEEP 1
 #endif
@@ -46,6 +52,7 @@ struct StackTraversal {
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
     uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
     const float4 *top = nullptr;   // LDS copy of the first SHRAY_LDS_TOP packed nodes (experiment, else unused)
+    int keep_dealt = kStackKeepWalkingDealt;   // a constant of the instance (kernel_stack.hip sets it before the first traversal)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -105,7 +112,7 @@ struct StackTraversal {
 #if SHRAY_RELATIVE_KEEP
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
-            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
+            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? keep_dealt : kStackKeepWalking) + 32) >> 6);
             if (PAIR) {
                 inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);

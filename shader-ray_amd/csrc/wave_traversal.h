@@ -49,6 +49,10 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 #ifndef SHRAY_TIED_ACCEPT
 #define SHRAY_TIED_ACCEPT 1
 #endif
+// experiment (off): the dealt stage's combine with DPP moves instead of ds_bpermute -- no faster (profiles/EXPERIMENTS.md R3.8)
+#ifndef SHRAY_DPP_COMBINE
+#define SHRAY_DPP_COMBINE 0
+#endif
 #ifndef SHRAY_BUFFER_LOADS
 #define SHRAY_BUFFER_LOADS 0
 #endif
@@ -545,6 +549,23 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
     return true;
 }
 
+// One exchange of the dealt stage's combine: every lane looks at the candidate of its partner under DPP control CTRL
+// (all 64 lanes execute; a row is 16 lanes) and keeps the better of the two.
+template <int CTRL>
+__device__ __forceinline__ void combine_dpp(float &best_d, float &best_u, float &best_w, uint32_t &best)
+{
+    const float od = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_d), CTRL, 0xf, 0xf, true));
+    const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)best, CTRL, 0xf, 0xf, true);
+    const float ou = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_u), CTRL, 0xf, 0xf, true));
+    const float ow = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_w), CTRL, 0xf, 0xf, true));
+    // (bitwise: four comparisons and three mask operations, no branches)
+    const bool take = (ob != 0xffffffffu) & ((best == 0xffffffffu) | (od < best_d) | ((od == best_d) & (ob > best)));
+    best_d = take ? od : best_d;
+    best_u = take ? ou : best_u;
+    best_w = take ? ow : best_w;
+    best = take ? ob : best;
+}
+
 // The search of a dealt stage: `parked` = the lanes in LT_LEAF (K of them, K <= SHRAY_DEAL_MAX_PARKED).  Returns true if
 // a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
 // (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its
@@ -615,6 +636,19 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
     }
     // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
+#if SHRAY_DPP_COMBINE
+    // A group is 2, 4, 8 or 16 neighbouring lanes, i.e. part of one DPP row: its lanes exchange candidates with
+    // data-parallel-primitive moves (one vector instruction each, no LDS round trip): neighbours in a quad, the quad's
+    // halves, the mirror image in a half row, the mirror image in the row.  Every exchange is between two lanes that both
+    // apply the same symmetric rule, so after the last one each lane of the group holds the group's winner.
+    combine_dpp<0xB1>(best_d, best_u, best_w, best);            // quad_perm [1, 0, 3, 2]
+    if (G > 2)
+        combine_dpp<0x4E>(best_d, best_u, best_w, best);        // quad_perm [2, 3, 0, 1]
+    if (G > 4)
+        combine_dpp<0x141>(best_d, best_u, best_w, best);       // row_half_mirror
+    if (G > 8)
+        combine_dpp<0x140>(best_d, best_u, best_w, best);       // row_mirror
+#else
     for (int step = 1; step < G; step <<= 1) {
         const int other = lane ^ step;
         const float od = lane_pull(other, best_d);
@@ -626,6 +660,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         best_w = take ? ow : best_w;
         best = take ? ob : best;
     }
+#endif
     // the parked lane collects its group's winner and moves on (fs:416-433)
     const int from = rank << log_g;
     wd = lane_pull(from, best_d);

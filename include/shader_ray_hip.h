@@ -314,6 +314,16 @@ int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *pa
                                 float *rgba_out_host /* may be NULL */,
                                 shray_counters *counters);
 
+/* Dispatch order ------------------------------------------------------------ */
+/* The batch kernels of plain (which == 0) frames start a launch's heaviest 16x16 patches first: every wave leaves its
+ * running time per patch, and every few launches of one shape (frame size, spp, tile set) the library re-sorts the
+ * patches for the launches that follow (csrc/capi.hip: DispatchOrder).  The frames do not depend on it; what does is
+ * how long a launch waits for its slowest waves when nothing follows it at once.  This call returns the permutation the
+ * next launch of the current shape would read: order_out[k] = the patch rendered by the launch's k-th patch slot.
+ * *count_out = its length (0: no shape yet, or the identity is still in use); at most `capacity` entries are written.
+ * It waits for the device.  The environment variable SHRAY_DISPATCH_ORDER=0 turns the re-ordering off for a process. */
+int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t capacity, uint32_t *count_out);
+
 /* Self-test ---------------------------------------------------------------- */
 /* Runs the kernel's 5-instruction "divide by a per-ray constant" (csrc/exact_div.h)
  * against true IEEE division on `pairs` pseudo-random operand pairs from the operand

@@ -127,6 +127,7 @@ HIP_SYMBOLS = [
                                         c_float_p, C.POINTER(Counters)]),
     ("shray_render_counters_timed", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
                                               c_float_p, C.POINTER(Counters)]),
+    ("shray_scene_dispatch_order", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
 ]
 

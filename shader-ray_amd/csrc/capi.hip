@@ -123,6 +123,30 @@ struct shray_scene {
     bool batch_pending[kBatchSlots] = {};
     int batch_next = 0;
 
+    // Dispatch order of the convergent batch kernels: heaviest patches first, learnt from the frames before.
+    // A frame's few long-running waves (rays grazing the silhouette, caught between the ears) last as long as a whole
+    // frame of average waves; in row-major order many of them start when a launch is almost over, and a launch that is
+    // not followed at once by another -- a rank's share of a step on 8 GPUs, the last launches of a short run -- waits
+    // for them with the machine empty (profiles/r03/heavy_first_probe.txt: a rank's 20-frame share at N = 8 takes 0.67
+    // instead of 0.98 ms).  Every wave leaves its running time in `cost` (per patch, the longest); every few launches a
+    // one-workgroup kernel behind the launch, on its stream, turns the costs into the next permutation
+    // (launch_dispatch_order); launches take it up once it is complete (`ready`, polled: no other stream ever waits for
+    // it, and no stream of the library's own competes with the caller's for hardware queues).  The ring is longer than the launches that can be in flight (kBatchSlots), so a
+    // permutation is never rewritten under a kernel that reads it.
+    struct DispatchOrder {
+        static constexpr int kRing = kBatchSlots + 2;
+        DeviceBuffer cost, ring;            // 2 n words (costs, the order kernel's copy); kRing * n words
+        uint32_t n = 0;
+        long long key[8] = {};              // the launch shape the costs belong to
+        int current = -1;                   // ring entry new launches read; -1: none yet (identity)
+        int written = -1;                   // ring entry the order kernel last wrote (or is writing): current once `ready`
+        unsigned long long launches = 0;    // since the shape was set
+        hipStream_t written_on = nullptr;   // the stream that order kernel was enqueued on: launches enqueued on it afterwards
+                                            // are ordered behind it and may read `written` at once
+        hipEvent_t ready = nullptr;
+        bool ready_pending = false;         // an order kernel has been enqueued and `written` is not current yet
+    } dispatch;
+
     // kernel id 4 (wavefront form): path queues, counts and per-sample radiances, grown on demand; one launch of a
     // scene at a time uses them (launches on different streams are ordered by wf_done)
     DeviceBuffer wf_queue0, wf_queue1, wf_counts, wf_radiance;
@@ -144,6 +168,8 @@ struct shray_scene {
             (void)hipStreamDestroy(readback_stream);
         if (wf_done)
             (void)hipEventDestroy(wf_done);
+        if (dispatch.ready)
+            (void)hipEventDestroy(dispatch.ready);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -442,6 +468,40 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
 //   * one spp == 1 frame per launch (latency): the frame ends with a tail of divergent waves, dealing wins by 11 %;
 //   * a cache-resident scene rendered for throughput (several frames per launch, or many samples per pixel):
 //     the GPU is full of coherent waves, the extra waves are worth more (3-6 %).
+// SHRAY_DISPATCH_ORDER: heaviest patches first in the convergent batch kernels (shray_scene::DispatchOrder);
+// the environment variable SHRAY_DISPATCH_ORDER=0 turns it off at run time (A/B, profiles/r03_dispatch_order_ab.sh)
+#ifndef SHRAY_DISPATCH_ORDER
+#define SHRAY_DISPATCH_ORDER 1
+#endif
+// launches of a shape between two re-sorts (tuning: SHRAY_DISPATCH_PERIOD)
+unsigned long long dispatch_period()
+{
+    static const unsigned long long period = [] {
+        const char *e = getenv("SHRAY_DISPATCH_PERIOD");
+        const long long v = e ? atoll(e) : 8;
+        return (unsigned long long)(v < 1 ? 1 : v);
+    }();
+    return period;
+}
+bool dispatch_order_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SHRAY_DISPATCH_ORDER");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// costs below (16 - bulk) / 16 of a shape's largest keep their row-major order among themselves (tuning: SHRAY_DISPATCH_BULK)
+int dispatch_bulk_class()
+{
+    static const int bulk = [] {
+        const char *e = getenv("SHRAY_DISPATCH_BULK");
+        return e ? atoi(e) : 1 << 20;    // every class of its own (measured: profiles/r03/dispatch_bulk_ab.txt)
+    }();
+    return bulk;
+}
+
 bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 {
     const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
@@ -499,6 +559,53 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
     FrameView *staged = scene->batch_staging + (size_t)slot * SHRAY_MAX_BATCH;
     FrameView *d_views = (FrameView *)scene->batch_views.p + (size_t)slot * SHRAY_MAX_BATCH;
     memcpy(staged, views, sizeof(FrameView) * (size_t)count);
+    // heaviest patches first (shray_scene::DispatchOrder): plain frames of the stack kernel's convergent instances
+    bool ordered = false;
+#if SHRAY_DISPATCH_ORDER
+    {
+        bool plain = scene->kernel_id == 0 || scene->kernel_id == 3;
+        for (int k = 0; k < count; k++)
+            plain = plain && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
+        // Where it pays (profiles/r03/dispatch_order_ab.txt): a launch that is not followed at once by more of the same -- one
+        // frame per launch (a lone frame: 0.54 -> 0.45 ms), a tile set (a rank's share of a multi-GPU step: 0.92 -> 0.74 ms for
+        // 20 frames at N = 8; within 3 % either way once steps follow each other without a gap).  Several whole frames per
+        // launch over several streams (the N = 1 throughput form) run 6 % SLOWER heaviest-first -- the long divergent waves
+        // of every launch then crowd the machine together -- and keep their row-major order.
+        const bool lone_kind = count == 1 || views[0].tile_stride != 0;
+        if (plain && !tally && lone_kind && dispatch_order_enabled()) {
+            shray_scene::DispatchOrder &d = scene->dispatch;
+            const FrameView &f = views[0];
+            const long long key[8] = {f.width, f.height, f.spp, f.tile_w, f.tile_h, f.tile_stride,
+                                      ((long long)f.tile_phase << 32) | (unsigned int)f.tile_phase_count, (long long)f.total_patches};
+            if (memcmp(key, d.key, sizeof(key)) != 0) {
+                // another launch shape: start over (launches of the old shape may still be running: new buffers)
+                if (!d.ready)
+                    HIP_TRY(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
+                HIP_TRY(hipDeviceSynchronize());
+                d.cost.release();
+                d.ring.release();
+                HIP_TRY(d.cost.upload(nullptr, (size_t)f.total_patches * 4 * 2));    // costs + the order kernel's copy of them
+                HIP_TRY(d.ring.upload(nullptr, (size_t)f.total_patches * 4 * shray_scene::DispatchOrder::kRing));
+                HIP_TRY(hipDeviceSynchronize());
+                memcpy(d.key, key, sizeof(key));
+                d.n = f.total_patches;
+                d.current = d.written = -1;
+                d.launches = 0;
+                d.ready_pending = false;
+            }
+            if (d.ready_pending && hipEventQuery(d.ready) == hipSuccess) {
+                d.current = d.written;      // the newest permutation is complete: this launch and its successors read it
+                d.ready_pending = false;
+            }
+            const int use = (d.ready_pending && stream == d.written_on) ? d.written : d.current;
+            for (int k = 0; k < count; k++) {
+                staged[k].dispatch_cost = (uint32_t *)d.cost.p;
+                staged[k].dispatch_order = use >= 0 ? (const uint32_t *)d.ring.p + (size_t)use * d.n : nullptr;
+            }
+            ordered = true;
+        }
+    }
+#endif
     HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
     bool all_metal = true;
     for (int k = 0; k < count; k++)
@@ -550,6 +657,24 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
     scene->batch_pending[slot] = true;
+#if SHRAY_DISPATCH_ORDER
+    if (ordered) {
+        // the next permutation: after each of the first launches of a shape, then every kDispatchPeriod launches
+        shray_scene::DispatchOrder &d = scene->dispatch;
+        d.launches++;
+        // (an update that is still pending on ANOTHER stream is not overtaken; on the same stream the kernels queue up)
+        if ((!d.ready_pending || stream == d.written_on) && (d.launches <= 3 || d.launches % dispatch_period() == 0)) {
+            const int next = (d.written + 1) % shray_scene::DispatchOrder::kRing;
+            const hipError_t oe = launch_dispatch_order((uint32_t *)d.cost.p, (uint32_t *)d.ring.p + (size_t)next * d.n, d.n, stream, dispatch_bulk_class());
+            if (oe != hipSuccess)
+                return fail(SHRAY_ERR_DEVICE, "dispatch-order kernel launch failed: %s", hipGetErrorString(oe));
+            HIP_TRY(hipEventRecord(d.ready, stream));
+            d.ready_pending = true;
+            d.written = next;
+            d.written_on = stream;
+        }
+    }
+#endif
     return SHRAY_OK;
 }
 
@@ -1218,6 +1343,27 @@ int shray_debug_set_patch_order(shray_scene *scene, const uint32_t *order, uint3
     return SHRAY_OK;
 }
 #endif
+
+int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t capacity, uint32_t *count_out)
+{
+    if (!scene || !count_out || (capacity && !order_out))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene, count_out or order_out is NULL");
+    HIP_TRY(hipSetDevice(scene->device));
+    shray_scene::DispatchOrder &d = scene->dispatch;
+    *count_out = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    if (d.ready_pending) {
+        d.current = d.written;
+        d.ready_pending = false;
+    }
+    if (d.current < 0 || d.n == 0)
+        return SHRAY_OK;
+    const uint32_t copy = capacity < d.n ? capacity : d.n;
+    if (copy)
+        HIP_TRY(hipMemcpy(order_out, (const uint32_t *)d.ring.p + (size_t)d.current * d.n, (size_t)copy * 4, hipMemcpyDeviceToHost));
+    *count_out = d.n;
+    return SHRAY_OK;
+}
 
 int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches)
 {

@@ -78,6 +78,10 @@ struct FrameView {
     // neighbouring lanes of a wave (uniform_driver.h); 0, 0 = one lane per pixel
     uint32_t sample_log_x, sample_log_y;
     const uint32_t *patch_order; // optional: workgroup b renders patch patch_order[b] (a permutation); nullptr = identity
+    // dispatch order of the convergent batch kernels (capi.hip: DispatchOrder): the launch's k-th patch slot renders patch
+    // dispatch_order[k] (nullptr = k), and every wave leaves how long it ran in dispatch_cost[patch] (nullptr = not asked)
+    const uint32_t *dispatch_order;
+    uint32_t *dispatch_cost;
 };
 
 struct DeviceCounters {

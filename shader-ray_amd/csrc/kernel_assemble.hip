@@ -54,4 +54,88 @@ hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// launch_dispatch_order: a stable counting sort of the patches by cost class, heaviest class first.
+#ifndef SHRAY_ORDER_CLASSES
+#define SHRAY_ORDER_CLASSES 32
+#endif
+constexpr int kOrderClasses = SHRAY_ORDER_CLASSES, kOrderThreads = 8192 / kOrderClasses;   // 32 KB of class counts in LDS
+
+__global__ void __launch_bounds__(kOrderThreads) dispatch_order_kernel(uint32_t *__restrict__ live_cost, uint32_t *__restrict__ order, uint32_t n,
+                                                                       uint32_t bulk_class)
+{
+    // render kernels keep reporting into live_cost while this runs: every pass below must see the SAME costs (or the
+    // classes' counts and the scatter disagree and `order` is no permutation), so they are copied first -- into the n
+    // words behind them -- and decay in place
+    uint32_t *__restrict__ cost = live_cost + n;
+    __shared__ uint32_t hist[kOrderClasses * kOrderThreads];   // hist[(class rank) * threads + thread], class rank 0 = heaviest
+    __shared__ uint32_t partial[kOrderThreads];
+    __shared__ uint32_t top;
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + kOrderThreads - 1) / kOrderThreads, first = t * chunk, last = min(n, first + chunk);
+    // the largest cost
+    uint32_t m = 0;
+    for (uint32_t e = first; e < last; e++) {
+        const uint32_t v = live_cost[e];
+        cost[e] = v;
+        live_cost[e] = v >> 1;     // (a wave that reports meanwhile may be overwritten: the next frame reports again)
+        m = max(m, v);
+    }
+    partial[t] = m;
+    __syncthreads();
+    for (uint32_t step = kOrderThreads / 2; step > 0; step >>= 1) {
+        if (t < step)
+            partial[t] = max(partial[t], partial[t + step]);
+        __syncthreads();
+    }
+    if (t == 0)
+        top = partial[0];
+    __syncthreads();
+    const unsigned long long scale = (unsigned long long)top + 1ull;
+    // this thread's patches per class
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; c++)
+        hist[c * kOrderThreads + t] = 0;
+    for (uint32_t e = first; e < last; e++) {
+        const uint32_t c = min(bulk_class, (kOrderClasses - 1) - (uint32_t)(((unsigned long long)cost[e] * kOrderClasses) / scale));
+        hist[c * kOrderThreads + t]++;
+    }
+    __syncthreads();
+    // exclusive scan over (class rank, thread): thread t owns kOrderClasses consecutive entries of the flattened table
+    uint32_t sum = 0;
+    for (int k = 0; k < kOrderClasses; k++)
+        sum += hist[t * kOrderClasses + k];
+    partial[t] = sum;
+    __syncthreads();
+    for (uint32_t step = 1; step < kOrderThreads; step <<= 1) {
+        const uint32_t add = t >= step ? partial[t - step] : 0u;
+        __syncthreads();
+        partial[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = partial[t] - sum;
+    for (int k = 0; k < kOrderClasses; k++) {
+        const uint32_t h = hist[t * kOrderClasses + k];
+        hist[t * kOrderClasses + k] = run;
+        run += h;
+    }
+    __syncthreads();
+    // scatter, in patch order inside a class
+    for (uint32_t e = first; e < last; e++) {
+        const uint32_t v = cost[e];
+        const uint32_t c = min(bulk_class, (kOrderClasses - 1) - (uint32_t)(((unsigned long long)v * kOrderClasses) / scale));
+        order[hist[c * kOrderThreads + t]++] = e;
+    }
+}
+
+hipError_t launch_dispatch_order(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream, int bulk_class)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t bulk = (uint32_t)(bulk_class < 0 ? 0 : (bulk_class > kOrderClasses - 1 ? kOrderClasses - 1 : bulk_class));
+    hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, n, bulk);
+    return hipGetLastError();
+}
+
 }   // namespace shray

@@ -45,6 +45,13 @@ struct PathState;
 hipError_t launch_wavefront(const SceneView &sc, const FrameView *d_view, const FrameView &fr, bool metal, PathState *queue0, PathState *queue1,
                             unsigned int *counts, float4 *radiance, float4 *out, hipStream_t stream, int stack_levels);
 
+// Dispatch order of the convergent batch kernels (kernel_assemble.hip): from the running times the waves left in
+// cost[0 .. n) (uniform_driver.h; cost[n .. 2n) is the kernel's scratch) writes the permutation order[0 .. n) -- patches by descending cost in 32 classes of
+// cost / max cost, patch order kept inside a class -- and halves every cost, so that
+// a patch stays where its last heavy frame put it until newer frames say otherwise.  One workgroup.
+// bulk_class: classes from this one on (costs below (16 - bulk_class) / 16 of the largest) count as one.
+hipError_t launch_dispatch_order(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream, int bulk_class);
+
 // rank 0's de-interleave (kernel_assemble.hip); strides in floats: rank_stride between ranks' buffers,
 // frame_stride between a rank's consecutive frames
 // (c0, c1): phases per period owned by rank 0 / by every other rank (1, 1 = even split)

@@ -45,6 +45,8 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     int px, py;
     size_t out_index;
     bool store, inside;
+    uint32_t *cost_slot = nullptr;          // where this wave leaves its running time (one-wave workgroups only)
+    unsigned long long cost_begin = 0;
     // lanes per pixel (multi-sample frames in one-wave workgroups only): G = gx * gy, this lane runs samples
     // sub, sub + G, ... of its pixel; base_lane = the pixel's lane with sub == 0
     const bool sample_lanes = !ONE_SAMPLE && (!COUNT || TIMED_FORM) && Traversal::block_size == 64;
@@ -58,9 +60,14 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
         // waves leave here.
         const unsigned int log_waves = 2u + log_gx + log_gy;
-        const unsigned int b = block_index, k = b >> 3, patch = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
-        if (patch >= fr.total_patches)
+        const unsigned int b = block_index, k = b >> 3, slot = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
+        if (slot >= fr.total_patches)
             return;
+        // heaviest patches first (capi.hip: DispatchOrder): which patch this slot of the launch renders
+        const unsigned int patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
+        cost_slot = fr.dispatch_cost ? fr.dispatch_cost + patch : nullptr;
+        if (cost_slot)
+            cost_begin = __builtin_amdgcn_s_memtime();
 #else
         const unsigned int log_waves = 2u + log_gx + log_gy;
         const unsigned int patch = block_index >> log_waves, wave = block_index & ((1u << log_waves) - 1u);
@@ -203,6 +210,11 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
         if (store)
             out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+    }
+    if (cost_slot && (threadIdx.x & 63u) == 0u) {
+        // the wave's running time in units of 64 shader-clock ticks: its patch keeps the longest of its waves' (and frames')
+        const unsigned long long ticks = (__builtin_amdgcn_s_memtime() - cost_begin) >> 6;
+        atomicMax(cost_slot, (uint32_t)(ticks > 0xffffffffull ? 0xffffffffull : ticks));
     }
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && (threadIdx.x & 63u) == 0) {

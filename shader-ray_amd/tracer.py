@@ -91,6 +91,16 @@ class Scene:
             out.ctypes.data_as(N.c_float_p) if want_image else None, C.byref(counters)))
         return out, counters.as_dict()
 
+    def dispatch_order(self) -> np.ndarray:
+        """The patch permutation the next batch launch of the current shape would read (shray_scene_dispatch_order);
+        empty while the identity is in use."""
+        n = C.c_uint32(0)
+        N.check(self._lib.shray_scene_dispatch_order(self._handle, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint32)
+        if n.value:
+            N.check(self._lib.shray_scene_dispatch_order(self._handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n)))
+        return out
+
     def render_into(self, params: N.FrameParams, width: int, height: int, spp: int, out_ptr: int,
                     stream_ptr: int = 0, tiles: N.TileSet | None = None):
         """Asynchronous render into device memory (`out_ptr`, e.g. tensor.data_ptr()) on a

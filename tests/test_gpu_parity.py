@@ -300,6 +300,54 @@ def test_tile_sets_reassemble_to_the_full_frame(pkg, gpu, bunny):
     scene.set_kernel(0)
 
 
+def test_dispatch_order_leaves_the_frames_alone(pkg, gpu, bunny):
+    """Heaviest patches first (shray_scene_dispatch_order): after a few launches of one shape the launches read a
+    learnt permutation of the patches -- a permutation it must be, the silhouette's patches in front, and every frame
+    bit-identical to the first launch's (which still ran in row-major order).  Lone whole frames and batches of a rank's
+    tile set, on two streams at once."""
+    import torch
+    world, desc, scene = bunny
+    N = pkg._native
+    W, H = 640, 360
+    frames = [world.frame_params(W, H, material=0)]
+    view = world.default_view()
+    for _ in range(3):
+        pkg.host.trackball_motion(view.object_rotation, 0.05, 0.02)
+        frames.append(world.frame_params(W, H, view, material=0))
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    # the library re-orders launches of one frame and launches of a tile set (capi.hip: launch_stack_views)
+    for tiles in (None, N.TileSet(32, 32, 3, 1, 2)):
+        nbytes = pkg.tracer.tile_buffer_bytes(W, H, tiles)
+
+        def launch(out, stream):
+            if tiles is None:
+                for k, frame in enumerate(frames):
+                    scene.render_into(frame, W, H, 1, out.data_ptr() + k * nbytes, stream.cuda_stream, None)
+            else:
+                scene.render_batch_into(frames, W, H, 1, out.data_ptr(), nbytes, stream.cuda_stream, tiles)
+
+        first = torch.empty(len(frames) * nbytes // 4, dtype=torch.float32, device="cuda:0")
+        launch(first, streams[0])
+        torch.cuda.synchronize()
+        again = [torch.empty_like(first) for _ in range(12)]
+        for j, out in enumerate(again):
+            launch(out, streams[j % 2])
+        torch.cuda.synchronize()
+        for out in again:
+            assert torch.equal(out, first), "a re-ordered launch changed a frame"
+        if os.environ.get("SHRAY_DISPATCH_ORDER") == "0":
+            continue
+        order = scene.dispatch_order()
+        patches = order.size
+        assert patches > 0 and np.array_equal(np.sort(order), np.arange(patches)), "not a permutation"
+        assert not np.array_equal(order, np.arange(patches)), "twelve launches and still the identity"
+    # a lone frame through shray_render (the same machinery, one frame per launch) against the counting twin's image
+    params = frames[1]
+    want, _ = scene.render_counters(params, W, H, 1)
+    for _ in range(5):
+        assert np.array_equal(scene.render(params, W, H, 1), want)
+
+
 def test_full_size_properties_1080p(pkg, gpu, oracle_mod, bunny, env_sky):
     """BASELINE config 2 size (1920x1080, gold): size-independent properties instead of a
     full CPU render -- kernel 0 == kernel 1 bit for bit, run-to-run determinism, alpha = 1,

@@ -470,9 +470,6 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
 //     the GPU is full of coherent waves, the extra waves are worth more (3-6 %).
 // SHRAY_DISPATCH_ORDER: heaviest patches first in the convergent batch kernels (shray_scene::DispatchOrder);
 // the environment variable SHRAY_DISPATCH_ORDER=0 turns it off at run time (A/B, profiles/r03_dispatch_order_ab.sh)
-#ifndef SHRAY_DISPATCH_ORDER
-#define SHRAY_DISPATCH_ORDER 1
-#endif
 // launches of a shape between two re-sorts (tuning: SHRAY_DISPATCH_PERIOD)
 unsigned long long dispatch_period()
 {
@@ -572,7 +569,14 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         // launch over several streams (the N = 1 throughput form) run 6 % SLOWER heaviest-first -- the long divergent waves
         // of every launch then crowd the machine together -- and keep their row-major order.
         const bool lone_kind = count == 1 || views[0].tile_stride != 0;
-        if (plain && !tally && lone_kind && dispatch_order_enabled()) {
+        bool zero_diffuse = true;     // (the instances that read an order exist for zero-diffuse frames: kernel_stack.hip)
+        for (int k = 0; k < count; k++)
+            zero_diffuse = zero_diffuse && !(views[k].diffuse_color[0] > 0.0f && views[k].diffuse_color[1] > 0.0f && views[k].diffuse_color[2] > 0.0f);
+        const bool pairs = plain && pair_policy(scene, views, count, policy_frames > 0 ? policy_frames : count);
+        // ... and for the instances that deal their leaves: every 1 spp launch, and multi-sample frames of a tree larger than
+        // an L2 share (config 4: 3.00 -> 2.74 ms); a cache-resident multi-sample frame (config 5) is 5 % SLOWER re-ordered
+        const bool dealing = views[0].spp == 1 || leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp);
+        if (plain && !tally && lone_kind && zero_diffuse && dealing && !pairs && dispatch_order_enabled()) {
             shray_scene::DispatchOrder &d = scene->dispatch;
             const FrameView &f = views[0];
             const long long key[8] = {f.width, f.height, f.spp, f.tile_w, f.tile_h, f.tile_stride,
@@ -652,7 +656,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
                              leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp), d_out, frame_stride, stream,
                              scene->stack_levels, tally, plain_view && pair_policy(scene, views, count, policy_frames > 0 ? policy_frames : count),
-                             tally_full_walk);
+                             tally_full_walk, ordered);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));

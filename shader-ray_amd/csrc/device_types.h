@@ -84,6 +84,12 @@ struct FrameView {
     uint32_t *dispatch_cost;
 };
 
+// SHRAY_DISPATCH_ORDER (1): heaviest patches first in the convergent batch kernels (capi.hip: DispatchOrder); 0 compiles
+// the waves' part of it out (A/B builds)
+#ifndef SHRAY_DISPATCH_ORDER
+#define SHRAY_DISPATCH_ORDER 1
+#endif
+
 struct DeviceCounters {
     unsigned long long node_visits, leaf_visits, triangle_tests, shaded_hits, env_lookups, traversals, bad_hits, samples;
 };

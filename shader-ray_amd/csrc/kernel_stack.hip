@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 // TALLY: 0 = the timed kernels; 1 = the same form with per-ray work tallies (what the timed form does); 2 = tallies of
 // the reference's walk (one lane per pixel, every shadow ray to its end) -- the counting twin of the pair traversal.
 // PAIR: both children of a node per turn (wave_traversal.h)
-template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR>
+template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR, bool ORDERED = false>
 __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,
                                                  int stack_levels, int frame_count_arg, DeviceCounters *counters)
 {
@@ -141,10 +141,10 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
         frame = rest % frame_count;
         block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
     }
-    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1, ORDERED>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
                                                                                block_index);
 #else
-    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1, ORDERED>(sc, frames[blockIdx.y], out + (size_t)blockIdx.y * frame_stride,
                                                                                counters, trav);
 #endif
 }
@@ -172,6 +172,16 @@ __global__ void __launch_bounds__(kBatchBlock, SHRAY_MIN_WAVES_DEALT_DENSE)
                                    int frame_count_arg)
 {
     stack_batch_body<true, true, true, 0, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+}
+
+// The zero-diffuse dealing instances once more for launches that read a dispatch order (capi.hip: DispatchOrder -- lone
+// frames, tile sets): DENSE = the seven-wave dealt instance of the throughput form (ONE_SAMPLE, DEAL)
+template <bool ONE_SAMPLE, bool DEAL, bool DENSE>
+__global__ void __launch_bounds__(kBatchBlock, DENSE ? SHRAY_MIN_WAVES_DEALT_DENSE : min_waves(true, DEAL, ONE_SAMPLE))
+    trace_stack_batch_ordered_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride, int stack_levels,
+                                     int frame_count_arg)
+{
+    stack_batch_body<ONE_SAMPLE, true, DEAL, 0, false, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
 }
 
 // The pair traversal (dealt leaf stage): for launches that are bound by dependent round trips -- a lone frame, a tree
@@ -228,7 +238,7 @@ static size_t stack_lds_bytes(int stack_levels, int block = kBlock)
 // `deal`: the dealt leaf stage instead of the plain one (capi.hip: leaf_stage_policy)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
-                              DeviceCounters *tally, bool pair, bool tally_full_walk)
+                              DeviceCounters *tally, bool pair, bool tally_full_walk, bool ordered)
 {
     // the view instances run 256-thread workgroups (a patch each), the convergent ones kBatchBlock-thread workgroups
     const bool view_instance = !all_plain;
@@ -305,6 +315,14 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
         SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<false, true>));
     else if (pair)
         SHRAY_LAUNCH_BATCH((trace_stack_batch_pair_kernel<false, false>));
+    // `ordered` (capi.hip: DispatchOrder; zero-diffuse launches only): the same choice among the instances that read a
+    // dispatch order
+    else if (ordered && metallic && dense)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_ordered_kernel<true, true, true>));
+    else if (ordered && metallic && one && deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_ordered_kernel<true, true, false>));
+    else if (ordered && metallic && !one && deal)
+        SHRAY_LAUNCH_BATCH((trace_stack_batch_ordered_kernel<false, true, false>));
     // `deal` (chosen in capi.hip: leaf_stage_policy) selects the leaf stage of each class of instances
     else if (dense)
         SHRAY_LAUNCH_BATCH(trace_stack_batch_dense_kernel);

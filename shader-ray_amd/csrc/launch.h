@@ -27,7 +27,8 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 // (kCounterShards copies) -- what the timed form does (shray_render_counters_timed)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
-                              DeviceCounters *tally = nullptr, bool pair = false, bool tally_full_walk = false);
+                              DeviceCounters *tally = nullptr, bool pair = false, bool tally_full_walk = false, bool ordered = false);
+// ordered: the frames carry a dispatch order / cost buffer (capi.hip: DispatchOrder): the instances that read them
 // pair: the instances that test both children of a node per turn (wave_traversal.h: inner_stage_pair; the scene needs
 // pair_nodes); tally_full_walk: with `tally` and `pair`, the tallies of the reference's walk instead of the timed form's
 

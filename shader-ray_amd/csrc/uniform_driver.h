@@ -30,7 +30,9 @@ namespace shray {
 // their tallies equal the reference's full traversals (the oracle's); with TIMED_FORM they keep the timed instances'
 // form instead -- sample lanes, shadow rays that stop at their first hit -- and tally what THOSE do
 // (shray_render_counters_timed).
-template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false>
+// ORDERED: the launch reads a dispatch order and its waves report their running times (capi.hip: DispatchOrder) -- an
+// instance of its own, because the two scalars it carries through the kernel cost the others 2 % (12 B more scratch)
+template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false, bool ORDERED = false>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool,
                                                      unsigned int block_index = 0xffffffffu)   // default: blockIdx.x
@@ -45,8 +47,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     int px, py;
     size_t out_index;
     bool store, inside;
-    uint32_t *cost_slot = nullptr;          // where this wave leaves its running time (one-wave workgroups only)
-    unsigned long long cost_begin = 0;
+    uint32_t cost_patch = 0xffffffffu, cost_begin = 0;   // ORDERED: the patch this wave reports its running time for
     // lanes per pixel (multi-sample frames in one-wave workgroups only): G = gx * gy, this lane runs samples
     // sub, sub + G, ... of its pixel; base_lane = the pixel's lane with sub == 0
     const bool sample_lanes = !ONE_SAMPLE && (!COUNT || TIMED_FORM) && Traversal::block_size == 64;
@@ -63,11 +64,14 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         const unsigned int b = block_index, k = b >> 3, slot = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
         if (slot >= fr.total_patches)
             return;
-        // heaviest patches first (capi.hip: DispatchOrder): which patch this slot of the launch renders
-        const unsigned int patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
-        cost_slot = fr.dispatch_cost ? fr.dispatch_cost + patch : nullptr;
-        if (cost_slot)
-            cost_begin = __builtin_amdgcn_s_memtime();
+        // heaviest patches first (capi.hip: DispatchOrder): which patch this slot of the launch renders, and when the wave
+        // began (two 32-bit scalars carried through the kernel: the patch and the low half of the shader clock)
+        unsigned int patch = slot;
+        if (ORDERED) {
+            patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
+            cost_patch = fr.dispatch_cost ? patch : 0xffffffffu;
+            cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
+        }
 #else
         const unsigned int log_waves = 2u + log_gx + log_gy;
         const unsigned int patch = block_index >> log_waves, wave = block_index & ((1u << log_waves) - 1u);
@@ -211,10 +215,10 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         if (store)
             out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
     }
-    if (cost_slot && (threadIdx.x & 63u) == 0u) {
-        // the wave's running time in units of 64 shader-clock ticks: its patch keeps the longest of its waves' (and frames')
-        const unsigned long long ticks = (__builtin_amdgcn_s_memtime() - cost_begin) >> 6;
-        atomicMax(cost_slot, (uint32_t)(ticks > 0xffffffffull ? 0xffffffffull : ticks));
+    if (ORDERED && cost_patch != 0xffffffffu && (threadIdx.x & 63u) == 0u) {
+        // the wave's running time in units of 64 shader-clock ticks (32-bit difference: good for 1.7 s): its patch keeps the
+        // longest of its waves' (and frames')
+        atomicMax(fr.dispatch_cost + cost_patch, ((uint32_t)__builtin_amdgcn_s_memtime() - cost_begin) >> 6);
     }
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && (threadIdx.x & 63u) == 0) {

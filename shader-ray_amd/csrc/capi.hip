@@ -145,7 +145,14 @@ struct shray_scene {
                                             // are ordered behind it and may read `written` at once
         hipEvent_t ready = nullptr;
         bool ready_pending = false;         // an order kernel has been enqueued and `written` is not current yet
-    } dispatch;
+        unsigned long long last_use = 0;    // (of the scene's launch counter: the least recently used shape makes room)
+    };
+    // a few shapes side by side (a caller that alternates between two frame sizes or tile sets keeps both orders; a new
+    // shape beyond that evicts the least recently used one, at the price of one device synchronisation)
+    static constexpr int kDispatchShapes = 4;
+    DispatchOrder dispatch[kDispatchShapes];
+    int dispatch_last = -1;                 // the shape of the most recent ordered launch (shray_scene_dispatch_order)
+    unsigned long long dispatch_clock = 0;
 
     // kernel id 4 (wavefront form): path queues, counts and per-sample radiances, grown on demand; one launch of a
     // scene at a time uses them (launches on different streams are ordered by wf_done)
@@ -168,8 +175,9 @@ struct shray_scene {
             (void)hipStreamDestroy(readback_stream);
         if (wf_done)
             (void)hipEventDestroy(wf_done);
-        if (dispatch.ready)
-            (void)hipEventDestroy(dispatch.ready);
+        for (DispatchOrder &d : dispatch)
+            if (d.ready)
+                (void)hipEventDestroy(d.ready);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -577,12 +585,24 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         // an L2 share (config 4: 3.00 -> 2.74 ms); a cache-resident multi-sample frame (config 5) is 5 % SLOWER re-ordered
         const bool dealing = views[0].spp == 1 || leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp);
         if (plain && !tally && lone_kind && zero_diffuse && dealing && !pairs && dispatch_order_enabled()) {
-            shray_scene::DispatchOrder &d = scene->dispatch;
             const FrameView &f = views[0];
             const long long key[8] = {f.width, f.height, f.spp, f.tile_w, f.tile_h, f.tile_stride,
                                       ((long long)f.tile_phase << 32) | (unsigned int)f.tile_phase_count, (long long)f.total_patches};
-            if (memcmp(key, d.key, sizeof(key)) != 0) {
-                // another launch shape: start over (launches of the old shape may still be running: new buffers)
+            int which = -1, lru = 0;
+            for (int k = 0; k < shray_scene::kDispatchShapes; k++) {
+                if (scene->dispatch[k].n && memcmp(key, scene->dispatch[k].key, sizeof(key)) == 0)
+                    which = k;
+                if (scene->dispatch[k].last_use < scene->dispatch[lru].last_use)
+                    lru = k;
+            }
+            const bool fresh = which < 0;
+            if (fresh)
+                which = lru;
+            scene->dispatch_last = which;
+            shray_scene::DispatchOrder &d = scene->dispatch[which];
+            d.last_use = ++scene->dispatch_clock;
+            if (fresh) {
+                // a shape not seen (lately): its slot starts over (launches of the evicted shape may still be running: new buffers)
                 if (!d.ready)
                     HIP_TRY(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
                 HIP_TRY(hipDeviceSynchronize());
@@ -664,7 +684,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
 #if SHRAY_DISPATCH_ORDER
     if (ordered) {
         // the next permutation: after each of the first launches of a shape, then every kDispatchPeriod launches
-        shray_scene::DispatchOrder &d = scene->dispatch;
+        shray_scene::DispatchOrder &d = scene->dispatch[scene->dispatch_last];
         d.launches++;
         // (an update that is still pending on ANOTHER stream is not overtaken; on the same stream the kernels queue up)
         if ((!d.ready_pending || stream == d.written_on) && (d.launches <= 3 || d.launches % dispatch_period() == 0)) {
@@ -1353,8 +1373,10 @@ int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t
     if (!scene || !count_out || (capacity && !order_out))
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene, count_out or order_out is NULL");
     HIP_TRY(hipSetDevice(scene->device));
-    shray_scene::DispatchOrder &d = scene->dispatch;
     *count_out = 0;
+    if (scene->dispatch_last < 0)
+        return SHRAY_OK;
+    shray_scene::DispatchOrder &d = scene->dispatch[scene->dispatch_last];
     HIP_TRY(hipDeviceSynchronize());
     if (d.ready_pending) {
         d.current = d.written;

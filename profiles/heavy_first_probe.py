@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: how much of a rank's lone launch (its tiles of K frames of the bench orbit, N ranks) is the late start of
-its heavy waves?  Needs a library built with -DSHRAY_EXPERIMENTS -DSHRAY_BATCH_PATCH_ORDER (SHRAY_HIP_LIB).
+its heavy waves?  Historical: it ran against an experiment build of commit 5a6d6ea's predecessor that took an explicit patch
+permutation for batch launches (-DSHRAY_EXPERIMENTS -DSHRAY_BATCH_PATCH_ORDER, since replaced by the learnt order of
+capi.hip: DispatchOrder); its output is quoted in profiles/EXPERIMENTS.md R3.9.
 Per-tile cost = the duration of a launch of that tile alone (its slowest wave), summed over the orbit's views; the
 rank's patches are then dispatched heaviest tile first.   python profiles/heavy_first_probe.py [N=8] [K=20]"""
 import ctypes as C

@@ -330,6 +330,9 @@ int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t
  * ranges it is used in, plus structured hard cases; *mismatches = number of pairs whose
  * results are not bit-identical (must be 0). */
 int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches);
+/* The kernels' three-instruction reciprocal (v_rcp_f32 and one Newton step in FMAs; csrc/exact_div.h) against true IEEE
+ * division on EVERY float of the domain it is used in (2^-100 <= |x| < 2^100, 3.4e9 values); *mismatches must be 0. */
+int shray_selftest_reciprocal(uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

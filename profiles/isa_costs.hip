@@ -6,6 +6,7 @@
 // left is one repetition of the stage -- the product's own inline functions (slab_range, triangle_distance,
 // triangle_barycentrics, shade_hit, environment, filmic, the primary-ray statements), compiled as the kernels compile
 // them.  Not linked into any library, never launched.
+#define SHRAY_COST_MAIN_PATH     // (the rare lanes' true divisions are not part of the count: wave_traversal.h)
 #include "stack_traversal.h"
 #include "uniform_driver.h"
 
@@ -115,7 +116,7 @@ __global__ void cost_traversal_setup(SceneView sc, const FrameView *frames, cons
     for (int k = 0; k < REPS; k++) {
         const float *r = rays + 16u * i + 1048576u * k;
         const V3 P = xform(fr.object_matrix, mk(r[0], r[1], r[2]), 1.0f), D = xform(fr.object_normal_matrix, mk(r[3], r[4], r[5]), 0.0f);
-        const V3 Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        const V3 Y = mk(reciprocal_in_range(D.x), reciprocal_in_range(D.y), reciprocal_in_range(D.z));   // (as lane_begin)
         const V3 YL = mk(reciprocal_residual(D.x, Y.x), reciprocal_residual(D.y, Y.y), reciprocal_residual(D.z, Y.z));
         float *o = out + 16u * i + 1048576u * k;
         o[0] = P.x; o[1] = P.y; o[2] = P.z; o[3] = D.x; o[4] = D.y; o[5] = D.z;

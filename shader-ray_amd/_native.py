@@ -129,6 +129,7 @@ HIP_SYMBOLS = [
                                               c_float_p, C.POINTER(Counters)]),
     ("shray_scene_dispatch_order", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("shray_selftest_reciprocal", C.c_int, [C.POINTER(C.c_uint64)]),
 ]
 
 HOST_SYMBOLS = [

@@ -1407,4 +1407,20 @@ int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches)
     return SHRAY_OK;
 }
 
+int shray_selftest_reciprocal(uint64_t *mismatches)
+{
+    if (!mismatches)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "mismatches is NULL");
+    DeviceBuffer count;
+    HIP_TRY(count.upload(nullptr, sizeof(unsigned long long)));
+    hipError_t e = shray::launch_reciprocal_selftest((unsigned long long *)count.p, nullptr);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "self-test launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, count.p, sizeof(n), hipMemcpyDeviceToHost));
+    *mismatches = n;
+    return SHRAY_OK;
+}
+
 }   // extern "C"

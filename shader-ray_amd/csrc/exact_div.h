@@ -49,6 +49,17 @@ __device__ __forceinline__ float div_by_constant4(float a, float b, float y, flo
     return __builtin_fmaf(r, y, q1);
 }
 
+// The correctly rounded reciprocal in three operations: the hardware's v_rcp_f32 (within 1 ulp) and ONE Newton step with
+// fused multiply-adds,   r = rcp(x);  e = fma(-x, r, 1);  r = fma(e, r, r),   equals RN(1 / x) for EVERY float with
+// 2^-100 <= |x| < 2^100 -- verified exhaustively, all 3.4e9 of them, by shray_selftest_reciprocal
+// (tests/test_gpu_selftest.py); the compiler's own 1.0f / x is ten (v_div_scale x2, v_rcp, five FMAs, v_div_fmas,
+// v_div_fixup: the scaling that protects intermediates outside that range).  Callers establish the range (or divide).
+__device__ __forceinline__ float reciprocal_in_range(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
 // exponent-field tests on the raw bits (NaN / inf fail every one of them)
 __device__ __forceinline__ bool magnitude_in(float v, int lo_exp, int hi_exp)   // 2^lo <= |v| < 2^(hi+1)
 {
@@ -56,6 +67,7 @@ __device__ __forceinline__ bool magnitude_in(float v, int lo_exp, int hi_exp)   
     return e >= lo_exp && e <= hi_exp;
 }
 __device__ __forceinline__ bool divisor_in_range(float b) { return magnitude_in(b, -40, 19); }
+__device__ __forceinline__ bool reciprocal_domain(float x) { return magnitude_in(x, -100, 99); }
 __device__ __forceinline__ bool coordinate_in_range(float c) { return c == 0.0f || magnitude_in(c, -70, 59); }
 
 }   // namespace shray

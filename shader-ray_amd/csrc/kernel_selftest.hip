@@ -63,4 +63,28 @@ hipError_t launch_division_selftest(unsigned long long pairs, unsigned long long
     return hipGetLastError();
 }
 
+
+// shray_selftest_reciprocal: reciprocal_in_range against the compiler's correctly rounded 1.0f / x on every float of its
+// domain (exponent field 27 .. 226, both signs: 200 * 2^23 * 2 values)
+__global__ void __launch_bounds__(256) reciprocal_selftest_kernel(unsigned long long *mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
+        const float x = __uint_as_float((uint32_t)u);
+        if (!reciprocal_domain(x))
+            continue;
+        if (__float_as_uint(reciprocal_in_range(x)) != __float_as_uint(1.0f / x))
+            bad++;
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reciprocal_selftest_kernel, dim3(4096), dim3(256), 0, stream, mismatches);
+    return hipGetLastError();
+}
+
 }   // namespace shray

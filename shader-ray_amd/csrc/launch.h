@@ -65,4 +65,7 @@ hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, 
 hipError_t launch_division_selftest(unsigned long long pairs, unsigned long long seed,
                                     unsigned long long *mismatches, hipStream_t stream);
 
+// reciprocal_in_range (exact_div.h) against 1.0f / x on every float of its domain; *mismatches receives the count.
+hipError_t launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t stream);
+
 }   // namespace shray

@@ -126,7 +126,16 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
     t.D = D;
     t.divide = !(sc.exact_div_ok && divisor_in_range(D.x) && divisor_in_range(D.y) && divisor_in_range(D.z) &&
                  coordinate_in_range(P.x) && coordinate_in_range(P.y) && coordinate_in_range(P.z));
-    t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    // RN(1 / D): a direction inside exact_div.h's divisor range is inside the three-instruction reciprocal's domain too;
+    // anything else divides (and its lane will go on dividing: t.divide)
+    t.Y = mk(reciprocal_in_range(D.x), reciprocal_in_range(D.y), reciprocal_in_range(D.z));
+#ifndef SHRAY_COST_MAIN_PATH
+    if (__builtin_expect(wave_ballot(t.divide) != 0ull, 0)) {
+        asm volatile("; a lane that divides" ::: "memory");   // keeps this a branch the wave skips
+        if (t.divide)
+            t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    }
+#endif
     t.YL = mk(reciprocal_residual(D.x, t.Y.x), reciprocal_residual(D.y, t.Y.y), reciprocal_residual(D.z, t.Y.z));
     t.fx = D.x >= 0.0f;
     t.fy = D.y >= 0.0f;
@@ -270,6 +279,25 @@ __device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &
     return lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
 }
 
+// 1 / det of triangle_intersect (fs:314).  A determinant the shader goes on with is at least 1e-7 (its early-out, fs:312);
+// below 2^100 (every scene of finite size) the three-instruction reciprocal of exact_div.h IS the correctly rounded
+// quotient; a larger one, or NaN, takes the true division (the wave skips it).  (triangle_candidate applies the early-out
+// after the arithmetic -- a conjunction --: what this returns for a determinant below 1e-7 is never looked at.)
+__device__ __forceinline__ float reciprocal_of_determinant(float det)
+{
+    float inv = reciprocal_in_range(det);
+#ifdef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes, not the division the rare one adds
+    return inv;
+#endif
+    const bool large = !(fabsf(det) < 0x1p100f);
+    if (__builtin_expect(wave_ballot(large) != 0ull, 0)) {
+        asm volatile("; determinant outside the reciprocal's domain" ::: "memory");   // keeps this a branch
+        if (large)
+            inv = 1.0f / det;
+    }
+    return inv;
+}
+
 // triangle_intersect (fs:297-346) in its two halves (profiles/isa_costs.py counts each in isolation).
 // First half, fs:307-331: determinant, distance, the early-outs against the determinant's epsilon, the closest hit so
 // far and the leaf's clipped range.  Returns false where the shader returns.
@@ -285,7 +313,7 @@ __device__ __forceinline__ bool triangle_distance(const LaneTraversal &t, const 
     const float det = dot3(e0, s.M);
     if (det > -0.0000001f && det < 0.0000001f)
         return false;
-    s.inv_det = 1.0f / det;
+    s.inv_det = reciprocal_of_determinant(det);
     s.T = t.P - v0;
     s.Q = cross3(s.T, e0);
     s.dist = -dot3(e1, s.Q) * s.inv_det;
@@ -532,7 +560,7 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
     const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
     const V3 M = cross3(e1, D);
     const float det = dot3(e0, M);
-    const float inv_det = 1.0f / det;
+    const float inv_det = reciprocal_of_determinant(det);
     const V3 T = P - v0;
     const V3 Q = cross3(T, e0);
     dist = -dot3(e1, Q) * inv_det;

@@ -313,7 +313,8 @@ int main(int argc, char **argv)
         printf("%d frames:\n", frames);
         const int buckets = 10;
         for (int b = 0; b < buckets; b++) {
-            const float start = lo + (hi - lo) * b / buckets, end = lo + (hi - lo) * (b + 1) / buckets;
+            // (the last bucket ends at the slowest frame itself: lo + (hi - lo) need not round back to hi)
+            const float start = lo + (hi - lo) * b / buckets, end = b == buckets - 1 ? hi : lo + (hi - lo) * (b + 1) / buckets;
             int count = 0;
             for (float d : frame_seconds)
                 if (d >= start && (d < end || (b == buckets - 1 && d <= end)))

@@ -11,7 +11,7 @@ region.  Rank 0 prints ONE JSON line.
 
 N = 1: the frame loop hands the C ABI four frames per launch (shray_render_batch_device) and alternates launches
 over four HIP streams.  N > 1 (one process per GPU): every rank drives libshray_dist.so (shray_dist_step): a step of
-the library carries 4 N consecutive frames -- the rank's interleaved tiles of each in one launch, RGB tile buffers
+the library carries 4 N consecutive frames (2 N in runs of fewer than 16 N) -- the rank's interleaved tiles of each in one launch, RGB tile buffers
 exchanged with grouped ncclSend / ncclRecv over xGMI, frame f of the step de-interleaved on rank f % N (rotating
 roots; --root-mode root0 gathers every frame on rank 0) -- and four such steps alternate on four streams and buffer
 sets.  Exactly K frames are rendered in the timed region either way (the last launch is shorter when the frames per
@@ -109,7 +109,7 @@ def main():
                     help="independent launches alternate over this many HIP streams (1 = strictly one at a time; default: 4)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames per launch (shray_render_batch_device / shray_dist_step).  Default: 4 for "
-                         "N = 1, 4 N for N > 1 (a step then carries four frames' worth of pixels per GPU)")
+                         "N = 1, 4 N for N > 1 (a step then carries four frames' worth of pixels per GPU; 2 N when --steps < 16 N)")
     ap.add_argument("--root-mode", choices=["rotate", "root0"], default="rotate",
                     help="N > 1: rotate = frame f of a step is assembled on rank f % N (all-to-all over every xGMI link); "
                          "root0 = every frame on rank 0 (gather)")
@@ -169,7 +169,12 @@ def main():
     lanes = max(1, args.frames_in_flight or 4)
     if distributed:
         lanes = min(lanes, 4)      # buffer sets of a shray_dist object
-    batch = max(1, min(64, args.frames_per_launch or (min(4 * world_size, max(1, args.steps)) if distributed else 4)))
+    # A run of fewer than four such steps takes 2 N frames per step instead: its compute side is the same within noise
+    # (profiles/r03/rank_share_steps.txt: a rank of 8 / 4 / 2 needs 0.65-0.73 / 1.24 / 2.44 ms for its share of 20 frames in
+    # steps of 2 N against 0.63-0.66 / 1.22 / 2.43 in one), but only the LAST step's exchange is left uncovered by rendering
+    # -- 4 of the driver's 20 frames at N = 8 instead of all 20 (9.3 MB per link, 0.09-0.19 ms of 0.9)
+    per_step = 4 * world_size if args.steps >= 16 * world_size else 2 * world_size
+    batch = max(1, min(64, args.frames_per_launch or (min(per_step, max(1, args.steps)) if distributed else 4)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = None
     me = None

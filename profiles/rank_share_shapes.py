@@ -63,7 +63,8 @@ whole = measure(None, 2, 4, K, W * H * 16)
 print(f"N = 1 loop (2 frames per launch x 4 streams), {K} frames: {whole:.3f} ms; ideal per rank at N = {N}: {whole / N:.3f} ms")
 tiles = Nn.TileSet(32, 32, N, N - 1, 1)
 stride = pkg.tracer.tile_buffer_bytes(W, H, tiles)
-for batch, lanes in sorted({(N, 2), (2 * N, 2), (2 * N, 4), (3 * N, 4), (4 * N, 4), (4 * N, 2), (-(-K // 4), 4), (-(-K // 2), 2), (-(-K // 3), 3), (N, 4), (max(1, N // 2), 4)}):
+custom = [(int(b), 4) for b in os.environ["SHAPES"].split(",")] if os.environ.get("SHAPES") else None   # SHAPES=8,16,20: frames per launch
+for batch, lanes in custom or sorted({(N, 2), (2 * N, 2), (2 * N, 4), (3 * N, 4), (4 * N, 4), (4 * N, 2), (-(-K // 4), 4), (-(-K // 2), 2), (-(-K // 3), 3), (N, 4), (max(1, N // 2), 4)}):
     if batch > 64:
         continue
     ms = measure(tiles, batch, lanes, K, stride)

@@ -346,6 +346,22 @@ def test_dispatch_order_leaves_the_frames_alone(pkg, gpu, bunny):
     want, _ = scene.render_counters(params, W, H, 1)
     for _ in range(5):
         assert np.array_equal(scene.render(params, W, H, 1), want)
+    # shapes side by side: a scene keeps the orders of its four most recent shapes (alternating between frame sizes must
+    # neither start over every time nor mix the permutations up), a fifth and sixth evict the oldest
+    sizes = [(320, 200), (200, 320), (256, 256), (640, 360), (128, 72), (96, 160)]
+    wants = {}
+    for w, h in sizes:
+        p = world.frame_params(w, h, view, material=0)
+        wants[(w, h)] = (p, scene.render_counters(p, w, h, 1)[0])
+    for _ in range(6):
+        for w, h in sizes:
+            p, want_frame = wants[(w, h)]
+            assert np.array_equal(scene.render(p, w, h, 1), want_frame), (w, h)
+            order = scene.dispatch_order()
+            patches = ((w + 15) // 16) * ((h + 15) // 16)
+            assert order.size in (0, patches), (w, h, order.size)
+            if order.size:
+                assert np.array_equal(np.sort(order), np.arange(patches))
 
 
 def test_full_size_properties_1080p(pkg, gpu, oracle_mod, bunny, env_sky):

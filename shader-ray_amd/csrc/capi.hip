@@ -497,6 +497,9 @@ bool dispatch_order_enabled()
     return on;
 }
 
+// a re-sort follows a shape's first three launches and every dispatch_period()-th from then on
+bool dispatch_sorts_after(unsigned long long launch_number) { return launch_number <= 3 || launch_number % dispatch_period() == 0; }
+
 // costs below (16 - bulk) / 16 of a shape's largest keep their row-major order among themselves (tuning: SHRAY_DISPATCH_BULK)
 int dispatch_bulk_class()
 {
@@ -622,8 +625,14 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
                 d.ready_pending = false;
             }
             const int use = (d.ready_pending && stream == d.written_on) ? d.written : d.current;
+            // only the launches a re-sort follows report their waves' running times: reporting costs a launch 3 % (a late
+            // scalar load of the buffer's address and an atomic per wave, profiles/r03/dispatch_mechanism_ab.txt)
+            // (the two launches before a re-sort: a loop that alternates long and short steps reports both)
+            // A launch of one frame always reports: its views change from launch to launch and the union of the last few is the
+            // better predictor (0.474 against 0.480 ms on the orbit).
+            const bool reports = count == 1 || dispatch_sorts_after(d.launches + 1) || dispatch_sorts_after(d.launches + 2);
             for (int k = 0; k < count; k++) {
-                staged[k].dispatch_cost = (uint32_t *)d.cost.p;
+                staged[k].dispatch_cost = reports ? (uint32_t *)d.cost.p : nullptr;
                 staged[k].dispatch_order = use >= 0 ? (const uint32_t *)d.ring.p + (size_t)use * d.n : nullptr;
             }
             ordered = true;
@@ -687,7 +696,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         shray_scene::DispatchOrder &d = scene->dispatch[scene->dispatch_last];
         d.launches++;
         // (an update that is still pending on ANOTHER stream is not overtaken; on the same stream the kernels queue up)
-        if ((!d.ready_pending || stream == d.written_on) && (d.launches <= 3 || d.launches % dispatch_period() == 0)) {
+        if ((!d.ready_pending || stream == d.written_on) && dispatch_sorts_after(d.launches)) {
             const int next = (d.written + 1) % shray_scene::DispatchOrder::kRing;
             const hipError_t oe = launch_dispatch_order((uint32_t *)d.cost.p, (uint32_t *)d.ring.p + (size_t)next * d.n, d.n, stream, dispatch_bulk_class());
             if (oe != hipSuccess)

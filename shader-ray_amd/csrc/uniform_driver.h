@@ -69,8 +69,9 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         unsigned int patch = slot;
         if (ORDERED) {
             patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
-            cost_patch = fr.dispatch_cost ? patch : 0xffffffffu;
-            cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
+            cost_patch = fr.dispatch_cost ? patch : 0xffffffffu;      // (only some launches report: capi.hip)
+            if (fr.dispatch_cost)
+                cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
         }
 #else
         const unsigned int log_waves = 2u + log_gx + log_gy;

@@ -127,8 +127,8 @@ struct shray_scene {
     // A frame's few long-running waves (rays grazing the silhouette, caught between the ears) last as long as a whole
     // frame of average waves; in row-major order many of them start when a launch is almost over, and a launch that is
     // not followed at once by another -- a rank's share of a step on 8 GPUs, the last launches of a short run -- waits
-    // for them with the machine empty (profiles/EXPERIMENTS.md R3.9: a rank's 20-frame share at N = 8 takes 0.64
-    // instead of 0.91 ms).  The waves of some launches leave their running time in `cost` (per patch, the longest); every few launches a
+    // for them with the machine empty (profiles/r03/heavy_first_probe.txt: a rank's 20-frame share at N = 8 takes 0.67
+    // instead of 0.98 ms).  Every wave leaves its running time in `cost` (per patch, the longest); every few launches a
     // one-workgroup kernel behind the launch, on its stream, turns the costs into the next permutation
     // (launch_dispatch_order); launches take it up once it is complete (`ready`, polled: no other stream ever waits for
     // it, and no stream of the library's own competes with the caller's for hardware queues).  The ring is longer than the launches that can be in flight (kBatchSlots), so a

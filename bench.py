@@ -17,9 +17,16 @@ roots; --root-mode root0 gathers every frame on rank 0) -- and four such steps a
 sets.  Exactly K frames are rendered in the timed region either way (the last launch is shorter when the frames per
 launch do not divide K).  torch.distributed (gloo) is the control plane only: rendezvous, barrier, max-over-ranks.
 
-For N > 1 launch as
+N > 1 runs one process per GPU.  Either launch them yourself,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+or just run `python bench.py --gpus N ...`: without WORLD_SIZE in the environment this process -- which makes no GPU call
+-- starts exactly that command as a child, relays rank 0's JSON line and exits with the child's code.
+
+The N > 1 line times BOTH root modes in the same run (`value` = the mode named in config.parallelism, the other under
+`alt_root_mode`) and carries `rccl_ranks` (ncclCommCount of the communicator the pixels travelled on), `frames_verified`
+(assembled frames compared bit for bit with single-GPU renders of the whole frame, after the timed region) and
+`transport_fallback`.
 """
 from __future__ import annotations
 
@@ -91,6 +98,22 @@ def algorithmic_ops(counters, costs):
             + k["c_env"] * c["env_lookups"] + k["c_pixel"] * c["samples"])
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process has made no GPU call (torch is not even imported); it
+    starts one rank per GPU with torch.distributed.run as a CHILD process (never an exec), passes its own arguments on,
+    relays the child's output (rank 0 prints the JSON line) and returns the child's exit code -- non-zero if any rank fails
+    (torch.distributed.run ends the other ranks and reports the failure)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd))
+    return subprocess.call(cmd)
+
+
 def main():
     global WIDTH, HEIGHT, SPP
     ap = argparse.ArgumentParser()
@@ -118,6 +141,9 @@ def main():
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -127,8 +153,8 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world_size and world_size == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if args.gpus != world_size and not (world_size == 1 and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world_size}: one process per GPU")
     # SHRAY_FORCE_DIST=1 rehearses the multi-GPU code path (process group, barrier, shray_dist_step) with one rank
     distributed = world_size > 1 or os.environ.get("SHRAY_FORCE_DIST") == "1"
     # Rehearsal on a single-GPU box: SHRAY_BENCH_ONE_GPU=1 puts every rank on cuda:0 and SHRAY_BENCH_TRANSPORT=gloo swaps
@@ -178,24 +204,27 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
     frame_outs = None
     me = None
+    ranks = {}             # root mode name -> multigpu.Rank (N > 1: both modes are timed, the chosen one first)
+    transport_fallback = False
+    rccl_ranks = None
     if distributed:
-        root_mode = multigpu.ROTATE if args.root_mode == "rotate" else multigpu.ROOT0
-        if transport_name == "gloo":
-            cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.CALLBACK, None, tile, tile,
+        mode_ids = {"rotate": multigpu.ROTATE, "root0": multigpu.ROOT0}
+
+        def make_rank(root_mode, transport):
+            """Collective.  (Rank or None, failure text or None) for `transport` = multigpu.RCCL / CALLBACK."""
+            cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, transport, None, tile, tile,
                                        not args.rgba_wire, buffer_sets=lanes)
-            me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
-        else:
-            failure = None
+            if transport == multigpu.CALLBACK:
+                return multigpu.Rank(scene, cfg, multigpu.HostExchange()), None
+            failure, made = None, None
             try:
                 ids = [multigpu.unique_id() if rank == 0 else None]
             except Exception as exc:   # noqa: BLE001
                 ids, failure = [None], repr(exc)
             dist.broadcast_object_list(ids, src=0)
-            cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.RCCL, None, tile, tile,
-                                       not args.rgba_wire, buffer_sets=lanes)
             if ids[0] is not None:
                 try:
-                    me = multigpu.Rank(scene, cfg, ids[0])      # collective: ncclCommInitRank
+                    made = multigpu.Rank(scene, cfg, ids[0])      # collective: ncclCommInitRank
                 except Exception as exc:   # noqa: BLE001
                     failure = repr(exc)
             else:
@@ -203,22 +232,37 @@ def main():
             failures = [None] * world_size
             dist.all_gather_object(failures, failure)
             if any(failures):
+                if made is not None:
+                    made.close()
+                return None, f"ranks {[k for k, f in enumerate(failures) if f]}: " + next(f for f in failures if f)
+            return made, None
+
+        for name in [args.root_mode] + [m for m in mode_ids if m != args.root_mode]:
+            if transport_name == "gloo":
+                ranks[name], _ = make_rank(mode_ids[name], multigpu.CALLBACK)
+                continue
+            made, failure = (None, "an earlier communicator failed") if transport_fallback else make_rank(mode_ids[name], multigpu.RCCL)
+            if made is None:
                 # a communicator that does not come up must not cost the whole measurement: every rank falls back to the
-                # host-staged exchange (slower: the tile buffers cross PCIe twice), and the line says so
+                # host-staged exchange (slower: the tile buffers cross PCIe twice); the line says so at top level
+                # (`transport_fallback`) and carries rccl_ranks = 0
                 if rank == 0:
-                    log("RCCL communicator failed on", [k for k, f in enumerate(failures) if f], ":", next(f for f in failures if f))
-                if me is not None:
-                    me.close()
-                transport_name = "gloo, host-staged (RCCL failed: " + next(f for f in failures if f)[:120] + ")"
-                cfg = multigpu.make_config(rank, world_size, WIDTH, HEIGHT, SPP, batch, root_mode, multigpu.CALLBACK, None, tile, tile,
-                                           not args.rgba_wire, buffer_sets=lanes)
-                me = multigpu.Rank(scene, cfg, multigpu.HostExchange())
+                    log("RCCL communicator failed:", failure)
+                if not transport_fallback:
+                    transport_name = "gloo, host-staged (RCCL failed: " + failure[:120] + ")"
+                transport_fallback = True
+                made, _ = make_rank(mode_ids[name], multigpu.CALLBACK)
+            ranks[name] = made
+        me = ranks[args.root_mode]
+        rccl_ranks = min(r.world()[1] for r in ranks.values())
     else:
         frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     trials = max(1, args.trials)
     starts, stops = [], []
     EVENT_STRIDE = max(1, int(os.environ.get("SHRAY_BENCH_EVENT_STRIDE", "4")))
     torch.cuda.synchronize()
+
+    active = {"rank": me}      # the shray_dist object the loop drives (N > 1: one per root mode)
 
     def views(first, count):
         return [orbit[(first + k) % ORBIT] for k in range(count)]
@@ -236,7 +280,7 @@ def main():
             stops.append(b)
             a.record(st)
         if distributed:
-            me.step(views(first, count), lane, st.cuda_stream)
+            active["rank"].step(views(first, count), lane, st.cuda_stream)
         elif count == 1:
             scene.render_into(orbit[first % ORBIT], WIDTH, HEIGHT, SPP, frame_outs[lane].data_ptr(), st.cuda_stream, None)
         else:
@@ -259,52 +303,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    fence()
-    # the clock of an idle GPU ramps for tens of milliseconds under load (round 2: ten 5 ms trials rose monotonically);
-    # keep rendering, untimed, until WARM_SECONDS have passed
-    t0 = time.perf_counter()
-    warm_frames = 0
-    while time.perf_counter() - t0 < WARM_SECONDS:
-        run(ORBIT)                 # whole periods of the orbit: a profile of this command averages over every view alike
-        warm_frames += ORBIT
+    def timed_trials():
+        """W warm-up steps, the clock ramp, then `trials` repetitions of the timed region; each one is EXACTLY K steps
+        between two fences (barrier + synchronize), its time the MAX over ranks.  Returns (seconds per trial, ms of the
+        untimed ramp, frames of it)."""
+        run(args.warmup)
         fence()
-    warm_ms = (time.perf_counter() - t0) * 1e3
-
-    # `trials` repetitions of the timed region; each one is EXACTLY K steps between two fences (barrier +
-    # synchronize), its time the MAX over ranks.  The median trial is what the JSON line reports, so that a
-    # short K (the driver's --steps 20 is 5 ms of GPU time) is not a single noisy sample.
-    trial_s = []
-    for trial in range(trials):
-        fence()
+        # the clock of an idle GPU ramps for tens of milliseconds under load (round 2: ten 5 ms trials rose
+        # monotonically); keep rendering, untimed, until WARM_SECONDS have passed
         t0 = time.perf_counter()
-        run(args.steps, timed=trial)
-        fence()
-        dt = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        trial_s.append(dt)
-    elapsed = sorted(trial_s)[len(trial_s) // 2]
+        ramp_frames = 0
+        while True:
+            run(ORBIT)             # whole periods of the orbit: a profile of this command averages over every view alike
+            ramp_frames += ORBIT
+            fence()
+            go_on = time.perf_counter() - t0 < WARM_SECONDS
+            if distributed:        # every rank leaves the ramp after the same number of (collective) steps
+                flag = torch.tensor([1 if go_on else 0])
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                go_on = bool(flag.item())
+            if not go_on:
+                break
+        ramp_ms = (time.perf_counter() - t0) * 1e3
+        seconds = []
+        for trial in range(trials):
+            fence()
+            t0 = time.perf_counter()
+            run(args.steps, timed=trial)
+            fence()
+            dt = time.perf_counter() - t0
+            if distributed:
+                t = torch.tensor([dt], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            seconds.append(dt)
+        return seconds, ramp_ms, ramp_frames
 
-    if distributed and os.environ.get("SHRAY_BENCH_CHECK") == "1":
-        # rehearsal aid (every rank takes part in the extra step): every assembled frame must equal a single-GPU
-        # render of the whole frame
-        me.step(views(0, batch), 0, streams[0].cuda_stream)
-        mine = me.frames(0, batch, streams[0].cuda_stream)
-        torch.cuda.synchronize()
+    def verify_frames():
+        """Outside the timed region: one more step, every frame this rank assembled compared bit for bit with a render
+        of the WHOLE frame on this rank's GPU (N = 1: the frames of one launch of the loop against one-frame launches).
+        Returns (frames compared over all ranks, frames that differed)."""
         whole = torch.empty(HEIGHT * WIDTH * 4, dtype=torch.float32, device=device)
-        same = True
-        for f, got in mine.items():
-            scene.render_into(orbit[f % ORBIT], WIDTH, HEIGHT, SPP, whole.data_ptr(), torch.cuda.current_stream().cuda_stream, None)
+        cur = torch.cuda.current_stream().cuda_stream
+        compared = differing = 0
+        if distributed:
+            for r in ranks.values():
+                r.step(views(0, batch), 0, streams[0].cuda_stream)
+                mine = r.frames(0, batch, streams[0].cuda_stream)
+                torch.cuda.synchronize()
+                for f, got in mine.items():
+                    scene.render_into(orbit[f % ORBIT], WIDTH, HEIGHT, SPP, whole.data_ptr(), cur, None)
+                    torch.cuda.synchronize()
+                    compared += 1
+                    differing += 0 if torch.equal(got.reshape(-1), whole) else 1
+            both = torch.tensor([compared, differing])
+            dist.all_reduce(both)
+            compared, differing = int(both[0]), int(both[1])
+        else:
+            step(0, 0, batch)
             torch.cuda.synchronize()
-            same = same and bool(torch.equal(got.reshape(-1), whole))
-        everyone = [None] * world_size
-        dist.all_gather_object(everyone, (sorted(mine), same))
-        if rank == 0:
-            frames_seen = sorted(f for fs, _ in everyone for f in fs)
-            log(f"assembled frames {frames_seen} of a step of {batch}; all equal the single-GPU frames:", all(ok for _, ok in everyone))
+            for k in range(batch):
+                scene.render_into(orbit[k % ORBIT], WIDTH, HEIGHT, SPP, whole.data_ptr(), cur, None)
+                torch.cuda.synchronize()
+                compared += 1
+                differing += 0 if torch.equal(frame_outs[0][k * HEIGHT * WIDTH * 4:(k + 1) * HEIGHT * WIDTH * 4], whole) else 1
+        return compared, differing
+
+    trial_s, warm_ms, warm_frames = timed_trials()
+    elapsed = sorted(trial_s)[len(trial_s) // 2]
+    alt = None
+    if distributed:
+        for name, r in ranks.items():
+            if name == args.root_mode:
+                continue
+            active["rank"] = r
+            starts.clear()
+            stops.clear()
+            alt_s, _, _ = timed_trials()
+            alt_elapsed = sorted(alt_s)[len(alt_s) // 2]
+            alt = {"mode": name, "value": round(WIDTH * HEIGHT * SPP * args.steps / alt_elapsed / 1e6, 3), "unit": "Mrays/s",
+                   "ms_per_step": round(alt_elapsed / args.steps * 1e3, 5), "trial_ms": [round(t * 1e3, 4) for t in alt_s],
+                   "what": ("every frame gathered on rank 0 (north_star's gather; link-bound at 1 spp: DESIGN.md section 6)"
+                            if name == "root0" else "frame f of a step assembled on rank f % N (all-to-all over every xGMI link)")}
+        active["rank"] = me
+    frames_compared, frames_differing = verify_frames()
 
     result = None
     frames_per_s = args.steps / elapsed
@@ -321,6 +403,8 @@ def main():
                       f"after the {args.warmup} warm-up steps the loop ran untimed for {warm_ms:.0f} ms ({warm_frames} frames) so that the "
                       "clock has ramped before the first trial",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "frames_verified": frames_compared - frames_differing, "frames_mismatched": frames_differing,
+            "rccl_ranks": rccl_ranks, "transport_fallback": transport_fallback,
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
                                    f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, "
                                    + ("gold" if args.material == 0 else f"material {args.material}") + ", 3 bounces"
@@ -474,11 +558,16 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pkg, desc, env, orbit[0])
     if rank == 0:
+        if alt is not None:
+            result["alt_root_mode"] = alt
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
-        me.close()
+        for r in ranks.values():
+            r.close()
         dist.destroy_process_group()
+    if frames_differing:
+        raise SystemExit(f"{frames_differing} of {frames_compared} verified frames differ from the single-GPU render")
 
 
 if __name__ == "__main__":

@@ -137,11 +137,18 @@ int shray_dist_create(shray_scene *scene, const shray_dist_config *config, const
                       shray_dist **out_dist);
 int shray_dist_destroy(shray_dist *dist);
 
+/* *world = the configuration's world; *communicator_ranks = how many ranks the transport's own communicator reports
+ * -- RCCL: ncclCommCount of the communicator shray_dist_create made (a measurement that claims N GPUs can show that RCCL
+ * really joined N of them) --, 0 for the LOOPBACK and CALLBACK transports, which have no communicator.  Either may be NULL. */
+int shray_dist_world(shray_dist *dist, int *world, int *communicator_ranks);
+
 /* One step: frames 0..count-1 rendered with params[0..count-1] (this rank's tiles, one launch), packed, exchanged
  * and de-interleaved on the ranks that own them.  Everything is enqueued: the render, pack and de-interleave on
  * hip_stream, the exchange on the object's own communication stream (ordered against hip_stream by events), so two
  * steps on two streams and two buffer sets overlap -- the exchange of one runs under the render of the next.
- * Nothing synchronises with the host (the CALLBACK transport does whatever its callee does). */
+ * Nothing synchronises with the host (the CALLBACK transport does whatever its callee does).  A buffer set may be driven
+ * from any stream: a step first makes hip_stream wait (on the device) for the end of the set's previous step.
+ * world == 1: the rank renders whole frames straight into the set's output (no pack, exchange or de-interleave). */
 int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *params, int count, void *hip_stream);
 
 /* After a step on `buffer_set` (and once hip_stream has reached that point): the frames this rank assembled.

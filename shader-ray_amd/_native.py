@@ -194,6 +194,7 @@ DIST_SYMBOLS = [
     ("shray_dist_hub_destroy", C.c_int, [C.c_void_p]),
     ("shray_dist_create", C.c_int, [C.c_void_p, C.POINTER(DistConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
     ("shray_dist_destroy", C.c_int, [C.c_void_p]),
+    ("shray_dist_world", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("shray_dist_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(FrameParams), C.c_int, C.c_void_p]),
     ("shray_dist_output", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_void_p)]),

@@ -121,38 +121,61 @@ struct shray_scene {
     DeviceBuffer batch_views;             // device, same shape
     hipEvent_t batch_done[kBatchSlots] = {};
     bool batch_pending[kBatchSlots] = {};
-    int batch_next = 0;
 
     // Dispatch order of the convergent batch kernels: heaviest patches first, learnt from the frames before.
     // A frame's few long-running waves (rays grazing the silhouette, caught between the ears) last as long as a whole
     // frame of average waves; in row-major order many of them start when a launch is almost over, and a launch that is
     // not followed at once by another -- a rank's share of a step on 8 GPUs, the last launches of a short run -- waits
-    // for them with the machine empty (profiles/r03/heavy_first_probe.txt: a rank's 20-frame share at N = 8 takes 0.67
-    // instead of 0.98 ms).  Every wave leaves its running time in `cost` (per patch, the longest); every few launches a
-    // one-workgroup kernel behind the launch, on its stream, turns the costs into the next permutation
-    // (launch_dispatch_order); launches take it up once it is complete (`ready`, polled: no other stream ever waits for
-    // it, and no stream of the library's own competes with the caller's for hardware queues).  The ring is longer than the launches that can be in flight (kBatchSlots), so a
-    // permutation is never rewritten under a kernel that reads it.
+    // for them with the machine empty (profiles/r03/dispatch_order_ab.txt: a rank's 20-frame share at N = 8 takes 0.64
+    // instead of 0.91 ms).  The waves of the launches a re-sort follows (of every one-frame launch) leave their running
+    // time in `cost` (per patch, the longest); every few launches a one-workgroup kernel behind the launch, on its
+    // stream, turns the costs into the next permutation (launch_dispatch_order); launches take a permutation up once it
+    // is complete (`ready[entry]`, polled: no other stream ever waits for it, and no stream of the library's own competes
+    // with the caller's for hardware queues).
+    // A ring entry is never rewritten while a launch may still read it: every entry remembers the last launch that was
+    // given it (`last_reader`, in the scene's launch numbers) and is written again only when that launch is known to be
+    // over -- the launch kBatchSlots launches later has waited for it (launch_stack_views) -- and when it is neither the
+    // entry new launches read nor one that is still being written; otherwise the re-sort is skipped (the next due launch
+    // tries again).
     struct DispatchOrder {
         static constexpr int kRing = kBatchSlots + 2;
         DeviceBuffer cost, ring;            // 2 n words (costs, the order kernel's copy); kRing * n words
-        uint32_t n = 0;
+        size_t capacity = 0;                // patches the two buffers were sized for
+        uint32_t n = 0;                     // 0: the slot holds no shape
         long long key[8] = {};              // the launch shape the costs belong to
         int current = -1;                   // ring entry new launches read; -1: none yet (identity)
-        int written = -1;                   // ring entry the order kernel last wrote (or is writing): current once `ready`
+        int written = -1;                   // ring entry the order kernel last wrote (or is writing)
+        int pending_first = 0, pending_count = 0;   // entries pending_first .. written (ring order) are enqueued, not known complete
         unsigned long long launches = 0;    // since the shape was set
-        hipStream_t written_on = nullptr;   // the stream that order kernel was enqueued on: launches enqueued on it afterwards
-                                            // are ordered behind it and may read `written` at once
-        hipEvent_t ready = nullptr;
-        bool ready_pending = false;         // an order kernel has been enqueued and `written` is not current yet
-        unsigned long long last_use = 0;    // (of the scene's launch counter: the least recently used shape makes room)
+        hipStream_t written_on = nullptr;   // the stream the pending order kernels were enqueued on: launches enqueued on it
+                                            // afterwards are ordered behind them and may read `written` at once
+        hipEvent_t ready[kRing] = {};       // recorded behind the order kernel that wrote the entry
+        unsigned long long last_reader[kRing] = {};   // scene launch number of the last launch given the entry (0: none)
+        unsigned long long last_use = 0;    // (of the scene's dispatch clock: the least recently used shape makes room)
     };
     // a few shapes side by side (a caller that alternates between two frame sizes or tile sets keeps both orders; a new
-    // shape beyond that evicts the least recently used one, at the price of one device synchronisation)
+    // shape beyond that evicts the least recently used one: its buffers are set aside until the launches that may read
+    // them are over (`retired`), nothing synchronises)
     static constexpr int kDispatchShapes = 4;
     DispatchOrder dispatch[kDispatchShapes];
     int dispatch_last = -1;                 // the shape of the most recent ordered launch (shray_scene_dispatch_order)
     unsigned long long dispatch_clock = 0;
+    unsigned long long launch_seq = 0;      // launches through launch_stack_views, 1-based; launch q uses batch slot (q - 1) % kBatchSlots
+    struct RetiredOrder {
+        DeviceBuffer cost, ring;
+        size_t capacity = 0;
+        unsigned long long retired_at = 0;  // the scene's launch number when the shape was evicted
+    };
+    std::vector<std::unique_ptr<RetiredOrder>> retired;
+    // a caller that rotates more shapes than there are slots would evict on every launch: shapes that come back after
+    // their eviction are counted (the last kEvictedKeys evicted keys are remembered), and after kThrashLimit of them without
+    // a launch that found its shape in place the scene's launches keep row-major order for the next kThrashPause launches
+    static constexpr int kEvictedKeys = 8, kThrashLimit = 8;
+    static constexpr unsigned long long kThrashPause = 256;
+    long long evicted_keys[kEvictedKeys][8] = {};
+    int evicted_next = 0;
+    int dispatch_returns = 0;               // evicted shapes that came back, since the last launch that found its shape in place
+    unsigned long long dispatch_paused_until = 0;   // launch number; ordering is off below it
 
     // kernel id 4 (wavefront form): path queues, counts and per-sample radiances, grown on demand; one launch of a
     // scene at a time uses them (launches on different streams are ordered by wf_done)
@@ -176,8 +199,9 @@ struct shray_scene {
         if (wf_done)
             (void)hipEventDestroy(wf_done);
         for (DispatchOrder &d : dispatch)
-            if (d.ready)
-                (void)hipEventDestroy(d.ready);
+            for (hipEvent_t e : d.ready)
+                if (e)
+                    (void)hipEventDestroy(e);
         for (int k = 0; k < kBatchSlots; k++)
             if (batch_done[k])
                 (void)hipEventDestroy(batch_done[k]);
@@ -548,6 +572,77 @@ bool pair_policy(const shray_scene *scene, const FrameView *views, int count, in
     return SHRAY_PAIR_POLICY == 1 && (divergent_scene || latency_launch);
 }
 
+// A dispatch-order slot starts over for a new launch shape.  Launches of the shape it held may still be running and
+// reading its buffers: those are set aside (shray_scene::retired) and handed out again only when every launch that was
+// enqueued before the eviction is over -- kBatchSlots launches later (launch_stack_views' slot wait) --, so nothing here
+// synchronises with the device.  `seq`: the current launch's number; `stream`: its stream (the new costs are zeroed on it:
+// a launch of the shape on ANOTHER stream that reports before the fill has run loses its report, which the next one
+// repeats).  A caller that rotates more shapes than there are slots would evict on every launch: shapes that come back
+// after their eviction are counted, and after kThrashLimit of them the scene's launches keep row-major order for a while
+// (shray_scene::dispatch_paused_until; the slot is then left as it is).
+int dispatch_slot_start(shray_scene *scene, shray_scene::DispatchOrder &d, const long long key[8], uint32_t patches,
+                        unsigned long long seq, hipStream_t stream)
+{
+    using Order = shray_scene::DispatchOrder;
+    // a shape that was evicted not long ago and is back: the caller rotates more shapes than there are slots
+    for (int k = 0; k < shray_scene::kEvictedKeys; k++)
+        if (memcmp(scene->evicted_keys[k], key, sizeof(scene->evicted_keys[k])) == 0 && key[7] != 0) {
+            if (++scene->dispatch_returns >= shray_scene::kThrashLimit) {
+                scene->dispatch_returns = 0;
+                scene->dispatch_paused_until = seq + shray_scene::kThrashPause;
+                scene->dispatch_last = -1;
+                return SHRAY_OK;
+            }
+            break;
+        }
+    if (d.n) {
+        memcpy(scene->evicted_keys[scene->evicted_next], d.key, sizeof(d.key));
+        scene->evicted_next = (scene->evicted_next + 1) % shray_scene::kEvictedKeys;
+        d.n = 0;                                   // from here on the slot matches no key, whatever fails below
+        std::unique_ptr<shray_scene::RetiredOrder> r(new shray_scene::RetiredOrder);
+        std::swap(r->cost.p, d.cost.p);
+        std::swap(r->ring.p, d.ring.p);
+        r->capacity = d.capacity;
+        r->retired_at = seq;
+        d.capacity = 0;
+        scene->retired.push_back(std::move(r));
+    }
+    // buffers: a retired pair that is large enough and no longer read, else new ones
+    for (size_t k = 0; k < scene->retired.size() && !d.cost.p; k++) {
+        shray_scene::RetiredOrder &r = *scene->retired[k];
+        if (r.capacity >= patches && seq >= r.retired_at + shray_scene::kBatchSlots) {
+            std::swap(d.cost.p, r.cost.p);
+            std::swap(d.ring.p, r.ring.p);
+            d.capacity = r.capacity;
+            scene->retired.erase(scene->retired.begin() + (long)k);
+        }
+    }
+    if (!d.cost.p) {
+        // more than a handful set aside: free the ones nobody reads any more (hipFree waits for the device: rare, and only here)
+        for (size_t k = 0; scene->retired.size() > 8 && k < scene->retired.size();) {
+            if (seq >= scene->retired[k]->retired_at + shray_scene::kBatchSlots)
+                scene->retired.erase(scene->retired.begin() + (long)k);
+            else
+                k++;
+        }
+        HIP_TRY(hipMalloc(&d.cost.p, (size_t)patches * 4 * 2));              // costs + the order kernel's copy of them
+        HIP_TRY(hipMalloc(&d.ring.p, (size_t)patches * 4 * Order::kRing));
+        d.capacity = patches;
+    }
+    HIP_TRY(hipMemsetAsync(d.cost.p, 0, (size_t)patches * 4 * 2, stream));
+    for (hipEvent_t &e : d.ready)
+        if (!e)
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    memcpy(d.key, key, sizeof(d.key));
+    d.current = d.written = -1;
+    d.pending_first = d.pending_count = 0;
+    d.launches = 0;
+    d.written_on = nullptr;
+    memset(d.last_reader, 0, sizeof(d.last_reader));
+    d.n = patches;
+    return SHRAY_OK;
+}
+
 int launch_stack_views(shray_scene *scene, const FrameView *views, int count, float4 *d_out, size_t frame_stride,
                        hipStream_t stream, DeviceCounters *tally = nullptr, int policy_frames = 0, bool tally_full_walk = false)
 {
@@ -560,8 +655,10 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         for (int k = 0; k < shray_scene::kBatchSlots; k++)
             HIP_TRY(hipEventCreateWithFlags(&scene->batch_done[k], hipEventDisableTiming));
     }
-    const int slot = scene->batch_next;
-    scene->batch_next = (slot + 1) % shray_scene::kBatchSlots;
+    // launch number `seq` uses slot (seq - 1) % kBatchSlots and first waits for the launch that used it before: once this
+    // wait has returned, every launch up to seq - kBatchSlots is over (each was waited for by its slot's next user)
+    const unsigned long long seq = ++scene->launch_seq;
+    const int slot = (int)((seq - 1) % shray_scene::kBatchSlots);
     if (scene->batch_pending[slot])
         HIP_TRY(hipEventSynchronize(scene->batch_done[slot]));   // rarely waits: the launch kBatchSlots launches ago
     FrameView *staged = scene->batch_staging + (size_t)slot * SHRAY_MAX_BATCH;
@@ -587,7 +684,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         // ... and for the instances that deal their leaves: every 1 spp launch, and multi-sample frames of a tree larger than
         // an L2 share (config 4: 3.00 -> 2.74 ms); a cache-resident multi-sample frame (config 5) is 5 % SLOWER re-ordered
         const bool dealing = views[0].spp == 1 || leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp);
-        if (plain && !tally && lone_kind && zero_diffuse && dealing && !pairs && dispatch_order_enabled()) {
+        if (plain && !tally && lone_kind && zero_diffuse && dealing && !pairs && dispatch_order_enabled() && seq >= scene->dispatch_paused_until) {
             const FrameView &f = views[0];
             const long long key[8] = {f.width, f.height, f.spp, f.tile_w, f.tile_h, f.tile_stride,
                                       ((long long)f.tile_phase << 32) | (unsigned int)f.tile_phase_count, (long long)f.total_patches};
@@ -598,44 +695,40 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
                 if (scene->dispatch[k].last_use < scene->dispatch[lru].last_use)
                     lru = k;
             }
-            const bool fresh = which < 0;
-            if (fresh)
-                which = lru;
-            scene->dispatch_last = which;
-            shray_scene::DispatchOrder &d = scene->dispatch[which];
-            d.last_use = ++scene->dispatch_clock;
-            if (fresh) {
-                // a shape not seen (lately): its slot starts over (launches of the evicted shape may still be running: new buffers)
-                if (!d.ready)
-                    HIP_TRY(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
-                HIP_TRY(hipDeviceSynchronize());
-                d.cost.release();
-                d.ring.release();
-                HIP_TRY(d.cost.upload(nullptr, (size_t)f.total_patches * 4 * 2));    // costs + the order kernel's copy of them
-                HIP_TRY(d.ring.upload(nullptr, (size_t)f.total_patches * 4 * shray_scene::DispatchOrder::kRing));
-                HIP_TRY(hipDeviceSynchronize());
-                memcpy(d.key, key, sizeof(key));
-                d.n = f.total_patches;
-                d.current = d.written = -1;
-                d.launches = 0;
-                d.ready_pending = false;
+            if (which >= 0) {
+                scene->dispatch_returns = 0;
+            } else {
+                // a shape not seen (lately) takes the least recently used slot
+                const int rc = dispatch_slot_start(scene, scene->dispatch[lru], key, f.total_patches, seq, stream);
+                if (rc)
+                    return rc;
+                which = seq < scene->dispatch_paused_until ? -1 : lru;   // (-1: too many shapes in rotation, row-major for a while)
             }
-            if (d.ready_pending && hipEventQuery(d.ready) == hipSuccess) {
-                d.current = d.written;      // the newest permutation is complete: this launch and its successors read it
-                d.ready_pending = false;
+            if (which >= 0) {
+                scene->dispatch_last = which;
+                shray_scene::DispatchOrder &d = scene->dispatch[which];
+                d.last_use = ++scene->dispatch_clock;
+                // permutations that have become complete, oldest first (the pending order kernels sit on one stream, in order)
+                while (d.pending_count > 0 && hipEventQuery(d.ready[d.pending_first]) == hipSuccess) {
+                    d.current = d.pending_first;
+                    d.pending_first = (d.pending_first + 1) % shray_scene::DispatchOrder::kRing;
+                    d.pending_count--;
+                }
+                const int use = (d.pending_count > 0 && stream == d.written_on) ? d.written : d.current;
+                if (use >= 0)
+                    d.last_reader[use] = seq;
+                // only the launches a re-sort follows report their waves' running times: reporting costs a launch 3 % (a late
+                // scalar load of the buffer's address and an atomic per wave, profiles/r03/dispatch_mechanism_ab.txt)
+                // (the two launches before a re-sort: a loop that alternates long and short steps reports both)
+                // A launch of one frame always reports: its views change from launch to launch and the union of the last few is
+                // the better predictor (0.474 against 0.480 ms on the orbit).
+                const bool reports = count == 1 || dispatch_sorts_after(d.launches + 1) || dispatch_sorts_after(d.launches + 2);
+                for (int k = 0; k < count; k++) {
+                    staged[k].dispatch_cost = reports ? (uint32_t *)d.cost.p : nullptr;
+                    staged[k].dispatch_order = use >= 0 ? (const uint32_t *)d.ring.p + (size_t)use * d.n : nullptr;
+                }
+                ordered = true;
             }
-            const int use = (d.ready_pending && stream == d.written_on) ? d.written : d.current;
-            // only the launches a re-sort follows report their waves' running times: reporting costs a launch 3 % (a late
-            // scalar load of the buffer's address and an atomic per wave, profiles/r03/dispatch_mechanism_ab.txt)
-            // (the two launches before a re-sort: a loop that alternates long and short steps reports both)
-            // A launch of one frame always reports: its views change from launch to launch and the union of the last few is the
-            // better predictor (0.474 against 0.480 ms on the orbit).
-            const bool reports = count == 1 || dispatch_sorts_after(d.launches + 1) || dispatch_sorts_after(d.launches + 2);
-            for (int k = 0; k < count; k++) {
-                staged[k].dispatch_cost = reports ? (uint32_t *)d.cost.p : nullptr;
-                staged[k].dispatch_order = use >= 0 ? (const uint32_t *)d.ring.p + (size_t)use * d.n : nullptr;
-            }
-            ordered = true;
         }
     }
 #endif
@@ -688,26 +781,38 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
                              tally_full_walk, ordered);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
-    scene->batch_pending[slot] = true;
 #if SHRAY_DISPATCH_ORDER
     if (ordered) {
-        // the next permutation: after each of the first launches of a shape, then every kDispatchPeriod launches
-        shray_scene::DispatchOrder &d = scene->dispatch[scene->dispatch_last];
+        // the next permutation: after each of the first launches of a shape, then every dispatch_period() launches
+        using Order = shray_scene::DispatchOrder;
+        Order &d = scene->dispatch[scene->dispatch_last];
         d.launches++;
         // (an update that is still pending on ANOTHER stream is not overtaken; on the same stream the kernels queue up)
-        if ((!d.ready_pending || stream == d.written_on) && dispatch_sorts_after(d.launches)) {
-            const int next = (d.written + 1) % shray_scene::DispatchOrder::kRing;
-            const hipError_t oe = launch_dispatch_order((uint32_t *)d.cost.p, (uint32_t *)d.ring.p + (size_t)next * d.n, d.n, stream, dispatch_bulk_class());
-            if (oe != hipSuccess)
-                return fail(SHRAY_ERR_DEVICE, "dispatch-order kernel launch failed: %s", hipGetErrorString(oe));
-            HIP_TRY(hipEventRecord(d.ready, stream));
-            d.ready_pending = true;
-            d.written = next;
-            d.written_on = stream;
+        if ((d.pending_count == 0 || stream == d.written_on) && dispatch_sorts_after(d.launches)) {
+            const int next = (d.written + 1) % Order::kRing;
+            // `next` must be free: not the entry launches read, not one still being written, and not read by a launch that
+            // may still be running (its last reader is over once kBatchSlots more launches have been enqueued, see above);
+            // if it is not, this re-sort is skipped and the next due launch tries again
+            const bool ring_full = (d.current >= 0 ? 1 : 0) + d.pending_count >= Order::kRing;
+            const bool still_read = d.last_reader[next] != 0 && seq < d.last_reader[next] + shray_scene::kBatchSlots;
+            if (!ring_full && !still_read) {
+                const hipError_t oe = launch_dispatch_order((uint32_t *)d.cost.p, (uint32_t *)d.ring.p + (size_t)next * d.n, d.n, stream, dispatch_bulk_class());
+                if (oe != hipSuccess)
+                    return fail(SHRAY_ERR_DEVICE, "dispatch-order kernel launch failed: %s", hipGetErrorString(oe));
+                HIP_TRY(hipEventRecord(d.ready[next], stream));
+                if (d.pending_count == 0)
+                    d.pending_first = next;
+                d.pending_count++;
+                d.written = next;
+                d.written_on = stream;
+                d.last_reader[next] = 0;
+            }
         }
     }
 #endif
+    // (behind the order kernel, which reads and writes the shape's buffers: "launch seq is over" covers it)
+    HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
+    scene->batch_pending[slot] = true;
     return SHRAY_OK;
 }
 
@@ -849,8 +954,11 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         HIP_TRY(s->packed_nodes.upload(nodes.data(), nodes.size() * sizeof(PackedNode)));
         HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
         s->view.packed_root = packed_root;
-        // sibling pairs for the pair traversal: the record of an inner node holds both children's boxes and links
-        {
+        // sibling pairs for the pair traversal: the record of an inner node holds both children's boxes and links.
+        // A pair link keeps the child index in kPairIndexMask's 22 bits.  The float32-index check above already bounds
+        // a scene at 2^21 nodes (8 link tables x stride <= 2^24); a tree that ever got past that keeps no pair records,
+        // so pair_policy() answers false and kernel 3 runs the one-visit instances.
+        if (nodes.size() <= (size_t)kPairIndexMask + 1) {
             std::vector<PackedPair> pairs(nodes.size());
             memset(pairs.data(), 0, pairs.size() * sizeof(PackedPair));
             uint32_t largest = 0;
@@ -1387,9 +1495,9 @@ int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t
         return SHRAY_OK;
     shray_scene::DispatchOrder &d = scene->dispatch[scene->dispatch_last];
     HIP_TRY(hipDeviceSynchronize());
-    if (d.ready_pending) {
+    if (d.pending_count > 0) {
         d.current = d.written;
-        d.ready_pending = false;
+        d.pending_count = 0;
     }
     if (d.current < 0 || d.n == 0)
         return SHRAY_OK;

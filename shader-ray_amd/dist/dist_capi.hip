@@ -95,10 +95,21 @@ struct Transport {
     virtual int exchange(char *d_wire, const shray_dist_xfer *sends, int ns, char *d_gather, const shray_dist_xfer *recvs, int nr,
                          hipStream_t stream) = 0;
     virtual bool on_comm_stream() const { return true; }
+    // ranks the transport's own communicator reports (RCCL: ncclCommCount), or 0 where there is no such thing
+    virtual int communicator_ranks(int *ranks) const
+    {
+        *ranks = 0;
+        return SHRAY_OK;
+    }
 };
 
 struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
+    int communicator_ranks(int *ranks) const override
+    {
+        NCCL_TRY(ncclCommCount(comm, ranks));
+        return SHRAY_OK;
+    }
     ~RcclTransport() override
     {
         if (comm)
@@ -258,6 +269,8 @@ struct LoopbackTransport : Transport {
 struct BufferSet {
     void *rendered = nullptr, *wire = nullptr, *gather = nullptr, *output = nullptr;
     hipEvent_t packed = nullptr, exchanged = nullptr;
+    hipEvent_t finished = nullptr;      // recorded at the end of the last step that used the set, on that step's stream
+    bool used = false;
 };
 
 }   // namespace
@@ -286,6 +299,8 @@ struct shray_dist {
                 (void)hipEventDestroy(b.packed);
             if (b.exchanged)
                 (void)hipEventDestroy(b.exchanged);
+            if (b.finished)
+                (void)hipEventDestroy(b.finished);
         }
     }
 };
@@ -425,6 +440,14 @@ int shray_dist_create(shray_scene *scene, const shray_dist_config *config, const
     for (BufferSet &b : d->sets) {
         // plain allocations: every byte that is read later is written first by this step's own kernels or transfers
         // (a rank's wire / gather rows hold exactly its owned tiles; the de-interleave reads only those)
+        if (r.world == 1) {
+            // a lone rank renders whole frames straight into `output` (shray_dist_step): nothing to pack or gather
+            HIP_TRY(hipMalloc(&b.output, frame_bytes * (size_t)r.max_frames));
+            HIP_TRY(hipEventCreateWithFlags(&b.packed, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b.exchanged, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b.finished, hipEventDisableTiming));
+            continue;
+        }
         HIP_TRY(hipMalloc(&b.rendered, std::max<size_t>(16, (size_t)p.render_frame_stride_bytes * r.max_frames)));
         HIP_TRY(hipMalloc(&b.wire, std::max<size_t>(16, (size_t)p.wire_frame_stride_bytes * r.max_frames)));
         if (p.max_assembled > 0) {
@@ -433,6 +456,7 @@ int shray_dist_create(shray_scene *scene, const shray_dist_config *config, const
         }
         HIP_TRY(hipEventCreateWithFlags(&b.packed, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&b.exchanged, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b.finished, hipEventDisableTiming));
     }
     *out_dist = d.release();
     return SHRAY_OK;
@@ -457,6 +481,23 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
     BufferSet &b = dist->sets[(size_t)buffer_set];
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool rotate = r.root_mode == SHRAY_DIST_ROTATE;
+
+    // A buffer set is reused only when the step that used it last is over -- whichever stream that step ran on (a caller
+    // with more streams than sets, or one that pairs them differently from step to step, is ordered here; with the same
+    // stream as last time the wait is a no-op).  `finished` sits behind that step's de-interleave, which itself waited
+    // for its exchange: neither its sends from `wire` nor its receives into `gather` can still be in flight.
+    if (b.used)
+        HIP_TRY(hipStreamWaitEvent(stream, b.finished, 0));
+    b.used = true;
+
+    if (r.world == 1) {
+        // a lone rank owns every tile and assembles every frame (in both root modes): whole frames, row-major, straight
+        // into `output` -- the single-GPU path, no pack, no exchange, no de-interleave
+        SHRAY_TRY(shray_render_batch_device(dist->scene, params, count, r.width, r.height, dist->spp, nullptr, b.output,
+                                            (int64_t)r.width * r.height * 16, stream));
+        HIP_TRY(hipEventRecord(b.finished, stream));
+        return SHRAY_OK;
+    }
 
     // 1. this rank's tiles of all `count` frames, one launch
     if (p.owned_tiles > 0) {
@@ -503,6 +544,20 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
     if (assembled > 0)
         SHRAY_TRY(shray_assemble_tiles_split_device(b.gather, r.world, r.c0, r.c1, assembled, p.channels, p.gather_rank_stride_bytes,
                                                     p.gather_frame_stride_bytes, r.width, r.height, r.tile_w, r.tile_h, b.output, stream));
+    HIP_TRY(hipEventRecord(b.finished, stream));
+    return SHRAY_OK;
+}
+
+int shray_dist_world(shray_dist *dist, int *world, int *communicator_ranks)
+{
+    if (!dist)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "dist is NULL");
+    if (world)
+        *world = dist->r.world;
+    if (communicator_ranks) {
+        HIP_TRY(hipSetDevice(dist->device));
+        return dist->transport->communicator_ranks(communicator_ranks);
+    }
     return SHRAY_OK;
 }
 

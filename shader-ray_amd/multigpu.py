@@ -214,6 +214,12 @@ class Rank:
         N.check_dist(self._lib.shray_dist_copy_output(self._handle, buffer_set, count, C.c_void_p(out.data_ptr()), C.c_void_p(stream_ptr)))
         return {first + k * step: out[k] for k in range(asm)}
 
+    def world(self):
+        """(world of the configuration, ranks the transport's communicator reports: ncclCommCount for RCCL, else 0)."""
+        w, ranks = C.c_int(), C.c_int()
+        N.check_dist(self._lib.shray_dist_world(self._handle, C.byref(w), C.byref(ranks)))
+        return w.value, ranks.value
+
     def device_index(self) -> int:
         d = C.c_int()
         N.check(N.load_hip().shray_scene_device(self.scene._handle, C.byref(d)))

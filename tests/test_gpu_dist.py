@@ -127,6 +127,7 @@ def test_rccl_transport_with_one_rank(pkg, gpu):
         assert len(uid) == 128 and any(uid)
         cfg = multigpu.make_config(0, 1, W, H, 1, 3, mode, multigpu.RCCL)
         me = multigpu.Rank(scene, cfg, uid)
+        assert me.world() == (1, 1)         # (configured world, ncclCommCount of the communicator shray_dist_create made)
         params = [world.frame_params(W, H, material=m) for m in (0, 6, 2)]
         me.step(params, 0, torch.cuda.current_stream().cuda_stream)
         frames = me.frames(0, 3, torch.cuda.current_stream().cuda_stream)
@@ -145,6 +146,95 @@ def test_rccl_transport_with_one_rank(pkg, gpu):
         me.step([world.frame_params(W, H)], 5, 0)                                    # no such buffer set
     me.close()
     scene.close()
+
+
+def test_one_buffer_set_driven_from_two_streams(pkg, gpu):
+    """A buffer set is not tied to a stream: step k + 1 on the same set but another stream must wait, on
+    the device, for step k's exchange and de-interleave before its render and pack overwrite the set's buffers.  Three
+    loopback ranks, ONE buffer set, the stream alternating from step to step, nothing synchronised in between; every
+    step's frames are copied out on the stream of that step."""
+    import torch
+    from shader_ray_amd import multigpu
+    W, H, ranks, frames, steps = 333, 200, 3, 3, 6
+    env = pkg.scenes.environment_hdr_sky(128)
+    path = os.path.join(GOLDEN, "lobed_528.trisrc")
+    world = pkg.World(path)
+    desc = world.flatten()
+    view = world.default_view()
+    params = []
+    for s in range(steps):
+        row = []
+        for f in range(frames):
+            pkg.host.trackball_motion(view.object_rotation, 0.03, 0.01)
+            row.append(world.frame_params(W, H, view, material=(0, 6, 3)[(s + f) % 3]))
+        params.append(row)
+    hub = multigpu.Hub(ranks)
+    got, errors = {}, []
+    lock = threading.Lock()
+    barrier = threading.Barrier(ranks)
+
+    def body(rank):
+        try:
+            torch.cuda.set_device(0)
+            scene = pkg.Scene(desc, env, device=0)
+            me = multigpu.Rank(scene, multigpu.make_config(rank, ranks, W, H, 1, frames, multigpu.ROTATE, multigpu.LOOPBACK, None, 32, 32,
+                                                           True, buffer_sets=1), hub)
+            streams = [torch.cuda.Stream(device=0) for _ in range(2)]
+            barrier.wait()
+            mine = {}
+            for s in range(steps):
+                st = streams[s % 2].cuda_stream
+                me.step(params[s], 0, st)
+                for f, t in me.frames(0, frames, st).items():
+                    mine[(s, f)] = t
+            torch.cuda.synchronize()
+            with lock:
+                got.update({k: t.cpu().numpy() for k, t in mine.items()})
+            barrier.wait()
+            me.close()
+            scene.close()
+        except Exception as exc:   # noqa: BLE001
+            errors.append((rank, repr(exc)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    hub.close()
+    assert not errors, errors
+    scene = pkg.Scene(desc, env, device=0)
+    assert len(got) == steps * frames
+    for (s, f), frame in got.items():
+        assert np.array_equal(frame, scene.render(params[s][f], W, H, 1)), (s, f)
+    scene.close()
+
+
+def test_bench_launches_its_own_ranks(gpu, tmp_path):
+    """`python bench.py --gpus 2` with no launcher typed by hand: the parent makes no GPU call, starts
+    torch.distributed.run as a child, relays rank 0's line.  On this one-GPU box both ranks share cuda:0 and the tile
+    buffers travel over gloo (SHRAY_BENCH_ONE_GPU / SHRAY_BENCH_TRANSPORT: the rehearsal switches); the line must name
+    both root modes, the verified frames and the (absent) RCCL communicator."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SHRAY_BENCH_ONE_GPU="1", SHRAY_BENCH_TRANSPORT="gloo")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--trials", "2",
+                          "--width", "640", "--height", "360"], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
+    assert line["frames_mismatched"] == 0 and line["frames_verified"] >= 8       # a step of 4 frames in each root mode
+    assert line["rccl_ranks"] == 0 and line["transport_fallback"] is False       # gloo was asked for, nothing fell back
+    assert "rotating roots" in line["config"]["parallelism"]
+    assert line["alt_root_mode"]["mode"] == "root0" and line["alt_root_mode"]["value"] > 0
+    # a rank that fails must fail the command: an impossible frame size is refused by every rank's validation
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--trials", "1",
+                          "--width", "0", "--height", "360"], env=env, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0
 
 
 def _gloo_worker(rank, world_size, port, mode, out_path):

@@ -364,6 +364,35 @@ def test_dispatch_order_leaves_the_frames_alone(pkg, gpu, bunny):
                 assert np.array_equal(np.sort(order), np.arange(patches))
 
 
+def test_dispatch_order_soak_without_host_synchronisation(pkg, gpu, bunny):
+    """A long run that never synchronises with the host (what shray_dist_step's callers do): 480 one-frame launches
+    rotated over four streams, the host ahead of the GPU all the way.  The dispatch-order ring is rewritten ~60 times
+    meanwhile -- more often than it has entries -- and no permutation may be rewritten under a launch that still reads it
+    (a torn permutation renders some patches twice and leaves others stale): every one of the 480 frames
+    must equal its view's first render."""
+    import torch
+    world, desc, scene = bunny
+    W, H, LAUNCHES = 1280, 720, 480
+    view = world.default_view()
+    views, wants = [], []
+    for _ in range(4):
+        pkg.host.trackball_motion(view.object_rotation, 0.04, 0.015)
+        p = world.frame_params(W, H, view, material=0)
+        views.append(p)
+        wants.append(torch.from_numpy(scene.render_counters(p, W, H, 1)[0]).reshape(-1).to("cuda:0"))
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = torch.full((LAUNCHES, W * H * 4), -1.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    for j in range(LAUNCHES):
+        scene.render_into(views[j % 3], W, H, 1, outs[j].data_ptr(), streams[j % 4].cuda_stream, None)
+    torch.cuda.synchronize()
+    for j in range(LAUNCHES):
+        assert torch.equal(outs[j], wants[j % 3]), f"launch {j} of the soak differs from its view's frame"
+    if os.environ.get("SHRAY_DISPATCH_ORDER") != "0":
+        order = scene.dispatch_order()
+        assert np.array_equal(np.sort(order), np.arange(order.size)) and order.size == (W // 16) * (H // 16)
+
+
 def test_full_size_properties_1080p(pkg, gpu, oracle_mod, bunny, env_sky):
     """BASELINE config 2 size (1920x1080, gold): size-independent properties instead of a
     full CPU render -- kernel 0 == kernel 1 bit for bit, run-to-run determinism, alpha = 1,

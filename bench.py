@@ -50,8 +50,8 @@ ORBIT_DRAG = (0.025, 0.010)  # the mouse drag per frame, in window fractions (tr
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # VALU issue peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-instructions / s
-PMC_FILE = os.path.join("profiles", "r03", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
-ISA_COSTS = os.path.join("profiles", "r03", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
+PMC_FILE = os.path.join("profiles", "r04", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
+ISA_COSTS = os.path.join("profiles", "r04", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
 WARM_SECONDS = 0.15        # back-to-back frames before the first trial, beyond the W warm-up steps: the GPU's clock ramps
 
 

@@ -47,7 +47,7 @@ extern "C" {
  * shray_abi_version() before their first call.  1: round 1.  2: shray_tile_set grew tile_phase_count (20 bytes).
  * 3: round 3 (shray_scene_set_environment_storage, shray_render_counters_timed, shray_scene_dispatch_order,
  * shray_selftest_reciprocal, the shray_dist_* companion header). */
-#define SHRAY_ABI_VERSION 3
+#define SHRAY_ABI_VERSION 4
 
 enum {
     SHRAY_OK = 0,
@@ -334,6 +334,18 @@ int shray_selftest_division(uint64_t pairs, uint64_t seed, uint64_t *mismatches)
 /* The kernels' three-instruction reciprocal (v_rcp_f32 and one Newton step in FMAs; csrc/exact_div.h) against true IEEE
  * division on EVERY float of the domain it is used in (2^-100 <= |x| < 2^100, 3.4e9 values); *mismatches must be 0. */
 int shray_selftest_reciprocal(uint64_t *mismatches);
+
+/* Measurement aid (bench.py's roofline): the rate at which the GPU's vector L1 caches serve the access pattern of a node
+ * visit -- every lane of a wave reads whole 32-byte records (two 16-byte loads) of a table of `records` records, the 64
+ * lanes of one wave-instruction among `spread` consecutive records around a pseudo-random base (powers of two; spread 1 =
+ * the whole wave at one record, 64 = every lane elsewhere; with bit 31 set the lanes that share a record are runs of
+ * neighbouring lanes instead of a pseudo-random choice), `visits_per_lane` (a multiple of 8) visits per lane in `waves`
+ * one-wave workgroups, eight visits in flight per wave.  *seconds = the launch's duration (HIP events, second of two
+ * passes), *bytes_loaded = waves * popcount(lane_mask) * visits_per_lane * bytes_per_lane; only the lanes of lane_mask
+ * load; bytes_per_lane = 32 (the node's two 16-byte loads) or 16, 12, 8, 4 (one load of that width of the record's first bytes).  The traversal kernels' node and triangle fetches are bound
+ * by this rate, not by HBM. */
+int shray_probe_vector_cache(uint32_t records, uint32_t spread, uint32_t visits_per_lane, uint32_t waves, uint64_t lane_mask,
+                             int bytes_per_lane, double *seconds, uint64_t *bytes_loaded);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,6 @@ __device__ __forceinline__ LaneTraversal load_ray(const float *in)
     t.P = mk(r[0], r[1], r[2]);
     t.D = mk(r[3], r[4], r[5]);
     t.Y = mk(r[6], r[7], r[8]);
-    t.YL = mk(r[9], r[10], r[11]);
     t.fx = t.D.x >= 0.0f;
     t.fy = t.D.y >= 0.0f;
     t.fz = t.D.z >= 0.0f;
@@ -31,9 +30,24 @@ __device__ __forceinline__ LaneTraversal load_ray(const float *in)
     return t;
 }
 
-// one node visit's slab test + the hit decision (fs:200-217, :272-275, :400)
+// one node visit's slab test + the hit decision (fs:200-217, :272-275, :400) as the kernels make it since round 4
+// (wave_traversal.h: visit_decision -- the bounds that decide all but one visit in 10^5; cost_node_exact: the quotients)
 template <int REPS>
 __global__ void cost_node(const float *rays, const float4 *nodes, float *out)
+{
+    LaneTraversal t = load_ray(rays);
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < REPS; k++) {
+        const float4 lo = nodes[(2u * i + 0u) + 4096u * k], hi = nodes[(2u * i + 1u) + 4096u * k];
+        float r0, r1;
+        const bool enter = visit_decision(t, lo, hi, r0, r1);
+        out[i + 65536u * k] = enter ? r0 : r1;
+    }
+}
+
+template <int REPS>
+__global__ void cost_node_exact(const float *rays, const float4 *nodes, float *out)
 {
     LaneTraversal t = load_ray(rays);
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,7 +83,7 @@ __global__ void cost_triangle_distance(const float *rays, const float4 *tris, fl
 
 // the whole triangle test (fs:297-346); the difference to the first half is the barycentric part
 template <int REPS>
-__global__ void cost_triangle_full(const float *rays, const float4 *tris, float *out)
+__global__ void cost_triangle_full(SceneView sc, const float *rays, const float4 *tris, float *out)
 {
     LaneTraversal t = load_ray(rays);
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +91,7 @@ __global__ void cost_triangle_full(const float *rays, const float4 *tris, float 
 #pragma unroll
     for (int k = 0; k < REPS; k++) {
         const float4 q0 = tris[3u * i + 8192u * k], q1 = tris[3u * i + 1u + 8192u * k], q2 = tris[3u * i + 2u + 8192u * k];
-        lane_test_triangle_loaded<false>(t, i + 7u * k, rc, q0, q1, q2);
+        lane_test_triangle_loaded<false, false>(sc, t, i + 7u * k, rc, q0, q1, q2);
     }
     out[4u * i] = t.hit.t;
     out[4u * i + 1] = t.hit.which;
@@ -117,10 +131,9 @@ __global__ void cost_traversal_setup(SceneView sc, const FrameView *frames, cons
         const float *r = rays + 16u * i + 1048576u * k;
         const V3 P = xform(fr.object_matrix, mk(r[0], r[1], r[2]), 1.0f), D = xform(fr.object_normal_matrix, mk(r[3], r[4], r[5]), 0.0f);
         const V3 Y = mk(reciprocal_in_range(D.x), reciprocal_in_range(D.y), reciprocal_in_range(D.z));   // (as lane_begin)
-        const V3 YL = mk(reciprocal_residual(D.x, Y.x), reciprocal_residual(D.y, Y.y), reciprocal_residual(D.z, Y.z));
         float *o = out + 16u * i + 1048576u * k;
         o[0] = P.x; o[1] = P.y; o[2] = P.z; o[3] = D.x; o[4] = D.y; o[5] = D.z;
-        o[6] = Y.x; o[7] = Y.y; o[8] = Y.z; o[9] = YL.x; o[10] = YL.y; o[11] = YL.z;
+        o[6] = Y.x; o[7] = Y.y; o[8] = Y.z;
     }
 }
 
@@ -163,7 +176,8 @@ __global__ void cost_primary_and_tonemap(const FrameView *frames, const float *r
     template __global__ void K<2>(__VA_ARGS__);
 INSTANTIATE(cost_node, const float *, const float4 *, float *)
 INSTANTIATE(cost_triangle_distance, const float *, const float4 *, float *)
-INSTANTIATE(cost_triangle_full, const float *, const float4 *, float *)
+INSTANTIATE(cost_triangle_full, SceneView, const float *, const float4 *, float *)
+INSTANTIATE(cost_node_exact, const float *, const float4 *, float *)
 INSTANTIATE(cost_shade, SceneView, const FrameView *, const float *, float *)
 INSTANTIATE(cost_traversal_setup, SceneView, const FrameView *, const float *, float *)
 INSTANTIATE(cost_environment, SceneView, const float *, float *)

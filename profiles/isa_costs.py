@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VALU instructions per unit of the shader's own arithmetic, read off the ISA (no GPU needed).
 
-    python profiles/isa_costs.py [out.json]         (default profiles/r03/isa_costs.json)
+    python profiles/isa_costs.py [out.json]         (default profiles/r04/isa_costs.json)
 
 profiles/isa_costs.hip wraps each stage of the per-pixel path -- the product's inline functions, unchanged -- in a
 kernel that runs it once or twice; the difference of the two instances' VALU counts is one repetition of the stage.
@@ -44,6 +44,7 @@ def measure():
     return {
         "unit": "VALU instructions per lane per unit of work (static count of the whole stage, gfx950, the product's flags)",
         "c_node": stage("cost_node"),
+        "c_node_exact_quotients": stage("cost_node_exact"),
         "c_tri_distance": dist,
         "c_tri_barycentric": full - dist,
         "c_tri_full": full,
@@ -57,7 +58,7 @@ def measure():
 
 
 if __name__ == "__main__":
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03", "isa_costs.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "isa_costs.json")
     costs = measure()
     json.dump(costs, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in costs.items() if k.startswith("c_")}))

@@ -36,7 +36,7 @@ def resources(unit="kernel_stack", extra=()):
 
 
 if __name__ == "__main__":
-    unit = sys.argv[1] if len(sys.argv) > 1 else "kernel_stack"
+    unit = sys.argv[1] if len(sys.argv) > 1 else "kernel_stack_batch"
     for r in resources(unit, sys.argv[2:]):
         print(f"{r['pretty']:<64} vgpr {r.get('VGPRs', '?'):>3} sgpr {r.get('TotalSGPRs', '?'):>3} scratch {r.get('ScratchSize', '?'):>4} "
               f"occupancy {r.get('Occupancy', '?')}")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 4 evidence run: GPU tests, the rocprofv3 passes behind profiles/r04/pmc_headline.json, bench lines
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gputests.log 2>&1; echo "gpu tests exit $?"; tail -3 gpurun_out/gputests.log
+timeout -k 10 900 bash profiles/run_profile.sh r04_default 60 "--warmup 20" > gpurun_out/profile_r04_default.txt 2>&1; grep "trace_stack_batch_dense_kernel" gpurun_out/profile_r04_default.txt | head -2
+python profiles/make_pmc_json.py gpurun_out/prof_r04_default/summary.txt gpurun_out/pmc_headline.json "trace_stack_batch_dense_kernel" 4 > /dev/null
+cp gpurun_out/pmc_headline.json profiles/r04/pmc_headline.json
+timeout -k 10 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench exit $?"; tail -1 gpurun_out/bench_default.json | cut -c1-300
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_steps20.json 2> gpurun_out/bench_steps20.err; tail -1 gpurun_out/bench_steps20.json | cut -c1-300
+timeout -k 10 300 python bench.py --same-view --no-cpu-baseline > gpurun_out/bench_same_view.json 2>/dev/null; tail -1 gpurun_out/bench_same_view.json | cut -c1-300

@@ -16,7 +16,7 @@ HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip
 
 c_float_p = C.POINTER(C.c_float)
 ENV_FLOAT32, ENV_UNORM8 = 0, 1
-ABI_VERSION = 3   # SHRAY_ABI_VERSION of the header these structures mirror (tests/test_abi.py compares the two)
+ABI_VERSION = 4   # SHRAY_ABI_VERSION of the header these structures mirror (tests/test_abi.py compares the two)
 
 
 class SceneDesc(C.Structure):
@@ -130,6 +130,7 @@ HIP_SYMBOLS = [
     ("shray_scene_dispatch_order", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("shray_selftest_division", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("shray_selftest_reciprocal", C.c_int, [C.POINTER(C.c_uint64)]),
+    ("shray_probe_vector_cache", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 ]
 
 HOST_SYMBOLS = [

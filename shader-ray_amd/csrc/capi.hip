@@ -111,8 +111,6 @@ struct shray_scene {
     uint32_t max_leaf_count = 0;     // the largest leaf: the pair records keep min(count, 127) (packed_layout.h)
     DeviceBuffer env;
     DeviceBuffer counters;
-    DeviceBuffer patch_order;        // permutation of patch indices for the stack kernel (optional)
-    uint32_t patch_order_count = 0;
 
     // shray_render_batch_device: per-frame FrameViews travel through a small ring of slots
     // (pinned staging -> device); a slot is reused only after the launch that read it has finished
@@ -344,22 +342,6 @@ struct TreeBuilder {
         std::vector<uint32_t> order;
         order.reserve(n);
         std::vector<char> numbered(n, 0);
-#if defined(SHRAY_LDS_TOP) && SHRAY_LDS_TOP > 0
-        // experiment (kernel_stack.hip under the same flag): the top of the tree first, breadth first
-        {
-            std::vector<uint32_t> level(1, (uint32_t)d.tree_root);
-            for (size_t k = 0; k < level.size() && order.size() < (size_t)SHRAY_LDS_TOP; k++) {
-                const uint32_t g = level[k];
-                new_index[g] = (uint32_t)order.size();
-                order.push_back(g);
-                numbered[g] = 1;
-                if (neg[g] >= 0) {
-                    level.push_back((uint32_t)neg[g]);
-                    level.push_back((uint32_t)pos[g]);
-                }
-            }
-        }
-#endif
         std::vector<uint32_t> todo(1, (uint32_t)d.tree_root);
         while (!todo.empty()) {
             const uint32_t g = todo.back();
@@ -392,9 +374,6 @@ struct TreeBuilder {
 };
 
 // 1: multi-sample frames run a pixel's samples in neighbouring lanes (uniform_driver.h); 0: one lane per pixel
-#ifndef SHRAY_SAMPLE_LANES
-#define SHRAY_SAMPLE_LANES 1
-#endif
 // at most 2^5 = 32 lanes per pixel: plaster 64 spp 16.38 / 15.83 / 16.26 ms with up to 64 / 32 / 16 (profiles/sample_lanes_probe.sh)
 #ifndef SHRAY_SAMPLE_LANES_LOG2_MAX
 #define SHRAY_SAMPLE_LANES_LOG2_MAX 5
@@ -456,8 +435,6 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
         int log_g = 0;
         while (log_g < SHRAY_SAMPLE_LANES_LOG2_MAX && (2 << log_g) <= spp)
             log_g++;
-        if (!SHRAY_SAMPLE_LANES)
-            log_g = 0;
         fr->sample_log_x = (uint32_t)((log_g + 1) / 2);
         fr->sample_log_y = (uint32_t)(log_g / 2);
     }
@@ -515,7 +492,7 @@ unsigned long long dispatch_period()
 bool dispatch_order_enabled()
 {
     static const bool on = [] {
-        const char *e = getenv("SHRAY_DISPATCH_ORDER");
+        const char *e = getenv("1");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -538,9 +515,6 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 {
     const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
     const bool latency_launch = frames_in_launch == 1 && spp == 1;
-#ifdef SHRAY_FORCE_LEAF_STAGE   // experiment builds: 0 = always the plain stage, 1 = always the dealt one
-    return SHRAY_FORCE_LEAF_STAGE != 0;
-#endif
     return divergent_scene || latency_launch;
 }
 
@@ -549,27 +523,19 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 // ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
 // tally / policy_frames: shray_render_counters_timed -- the instance a launch of `policy_frames` frames would run, with
 // per-ray work tallies
-// Which launches of the stack kernel test both children of a node per turn (wave_traversal.h: inner_stage_pair).  The
-// pair form issues the same arithmetic and the same loads as the one-visit form but about 0.6 of its dependent round
-// trips, for a fatter turn: it pays where a launch is bound by the latency of its longest rays, not by issue slots.
-// SHRAY_PAIR_POLICY: 0 = only when the scene asks for it (shray_scene_set_kernel(scene, 3)), 1 = also for the launches
-// named below, 2 = every launch that can.
-#ifndef SHRAY_PAIR_POLICY
-#define SHRAY_PAIR_POLICY 0
-#endif
-bool pair_policy(const shray_scene *scene, const FrameView *views, int count, int frames_in_launch)
+// Which launches of the stack kernel test both children of a node per turn (wave_traversal.h: inner_stage_pair): those
+// of a scene that asked for it, shray_scene_set_kernel(scene, 3).  The pair form issues the same arithmetic and the same
+// loads as the one-visit form but about 0.6 of its dependent round trips, for a fatter turn; measured 24-35 % slower on
+// every configuration (profiles/EXPERIMENTS.md R3.2), so no launch chooses it by itself.
+bool pair_policy(const shray_scene *scene, const FrameView *views, int count)
 {
-    if (!scene->pair_nodes.p)
+    if (!scene->pair_nodes.p || scene->kernel_id != 3)
         return false;
     // a pair record keeps min(triangle count, 127): exact whenever the leaf cap or the largest leaf stays below that
     for (int k = 0; k < count; k++)
         if (scene->max_leaf_count > 126u && (uint32_t)views[k].max_leaf_tests > 126u)
             return false;
-    if (scene->kernel_id == 3 || SHRAY_PAIR_POLICY == 2)
-        return true;
-    const bool divergent_scene = (size_t)scene->view.group_count * sizeof(PackedNode) > (2u << 20);
-    const bool latency_launch = frames_in_launch == 1 && views[0].spp == 1;
-    return SHRAY_PAIR_POLICY == 1 && (divergent_scene || latency_launch);
+    return true;
 }
 
 // A dispatch-order slot starts over for a new launch shape.  Launches of the shape it held may still be running and
@@ -666,7 +632,6 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
     memcpy(staged, views, sizeof(FrameView) * (size_t)count);
     // heaviest patches first (shray_scene::DispatchOrder): plain frames of the stack kernel's convergent instances
     bool ordered = false;
-#if SHRAY_DISPATCH_ORDER
     {
         bool plain = scene->kernel_id == 0 || scene->kernel_id == 3;
         for (int k = 0; k < count; k++)
@@ -680,7 +645,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         bool zero_diffuse = true;     // (the instances that read an order exist for zero-diffuse frames: kernel_stack.hip)
         for (int k = 0; k < count; k++)
             zero_diffuse = zero_diffuse && !(views[k].diffuse_color[0] > 0.0f && views[k].diffuse_color[1] > 0.0f && views[k].diffuse_color[2] > 0.0f);
-        const bool pairs = plain && pair_policy(scene, views, count, policy_frames > 0 ? policy_frames : count);
+        const bool pairs = plain && pair_policy(scene, views, count);
         // ... and for the instances that deal their leaves: every 1 spp launch, and multi-sample frames of a tree larger than
         // an L2 share (config 4: 3.00 -> 2.74 ms); a cache-resident multi-sample frame (config 5) is 5 % SLOWER re-ordered
         const bool dealing = views[0].spp == 1 || leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp);
@@ -731,7 +696,6 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
             }
         }
     }
-#endif
     HIP_TRY(hipMemcpyAsync(d_views, staged, sizeof(FrameView) * (size_t)count, hipMemcpyHostToDevice, stream));
     bool all_metal = true;
     for (int k = 0; k < count; k++)
@@ -777,11 +741,10 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         ? launch_pool_batch(scene->view, d_views, count, views[0], all_metal, d_out, frame_stride, stream, scene->stack_levels)
         : launch_stack_batch(scene->view, d_views, count, views[0], all_metal, plain_view,
                              leaf_stage_policy(scene, policy_frames > 0 ? policy_frames : count, views[0].spp), d_out, frame_stride, stream,
-                             scene->stack_levels, tally, plain_view && pair_policy(scene, views, count, policy_frames > 0 ? policy_frames : count),
+                             scene->stack_levels, tally, plain_view && pair_policy(scene, views, count),
                              tally_full_walk, ordered);
     if (e != hipSuccess)
         return fail(SHRAY_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-#if SHRAY_DISPATCH_ORDER
     if (ordered) {
         // the next permutation: after each of the first launches of a shape, then every dispatch_period() launches
         using Order = shray_scene::DispatchOrder;
@@ -809,7 +772,6 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
             }
         }
     }
-#endif
     // (behind the order kernel, which reads and writes the shape's buffers: "launch seq is over" covers it)
     HIP_TRY(hipEventRecord(scene->batch_done[slot], stream));
     scene->batch_pending[slot] = true;
@@ -819,16 +781,15 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
 int launch(shray_scene *s, const FrameView &fr_in, float4 *d_out, DeviceCounters *d_counters, hipStream_t stream)
 {
     FrameView fr = fr_in;
-    fr.patch_order = (s->patch_order.p && s->patch_order_count == fr.total_patches) ? (const uint32_t *)s->patch_order.p : nullptr;
     if (fr.total_patches == 0)
         return SHRAY_OK;
     hipError_t e;
-    if (s->kernel_id != 1 && s->packed_ok && !d_counters && !fr.patch_order)
+    if (s->kernel_id != 1 && s->packed_ok && !d_counters)
         return launch_stack_views(s, &fr, 1, d_out, 0, stream);
     const bool view_instance = fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5;
-    if (s->kernel_id == 3 && s->packed_ok && d_counters && !fr.patch_order && !view_instance && pair_policy(s, &fr, 1, 1))
+    if (s->kernel_id == 3 && s->packed_ok && d_counters && !view_instance && pair_policy(s, &fr, 1))
         return launch_stack_views(s, &fr, 1, d_out, 0, stream, d_counters, 0, true);   // the pair traversal's own counting twin
-    else if (s->kernel_id == 2 && s->packed_ok && !fr.patch_order &&
+    else if (s->kernel_id == 2 && s->packed_ok &&
              !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5))
         e = launch_pool(s->view, fr, d_out, d_counters, stream, s->stack_levels);
     else if (s->kernel_id != 1 && s->packed_ok)
@@ -1198,7 +1159,7 @@ int shray_render_batch_device(shray_scene *scene, const shray_frame_params *para
     char *out = (char *)d_rgba_out;
 
     // anything but the stack kernel runs as plain consecutive launches
-    if (scene->kernel_id == 1 || scene->kernel_id == 4 || !scene->packed_ok || scene->patch_order.p) {
+    if (scene->kernel_id == 1 || scene->kernel_id == 4 || !scene->packed_ok) {
         for (int k = 0; k < count; k++) {
             const int rc = launch(scene, views[k], (float4 *)(out + (size_t)k * frame_stride_bytes), nullptr, stream);
             if (rc)
@@ -1396,7 +1357,7 @@ int shray_render_counters_timed(shray_scene *scene, const shray_frame_params *pa
         return fail(SHRAY_ERR_INVALID_ARGUMENT, "frames_per_launch %d (1..%d)", frames_per_launch, SHRAY_MAX_BATCH);
     const bool view = params->which == 1 || params->which == 2 || params->which == 3 || params->which == 5;
     // only the stack kernel's convergent instances have a timed form of their own; everything else is timed as it counts
-    if ((scene->kernel_id != 0 && scene->kernel_id != 3 && scene->kernel_id != 4) || !scene->packed_ok || view || scene->patch_order.p)
+    if ((scene->kernel_id != 0 && scene->kernel_id != 3 && scene->kernel_id != 4) || !scene->packed_ok || view)
         return shray_render_counters(scene, params, width, height, spp, rgba_out_host, counters);
     if (!scene->view.env)
         return fail(SHRAY_ERR_NO_ENVIRONMENT, "no environment set; call shray_scene_set_environment first");
@@ -1469,21 +1430,6 @@ int shray_debug_timeline(shray_scene *scene, const shray_frame_params *params, i
 }
 #endif
 
-#ifdef SHRAY_EXPERIMENTS
-// experiment hook: install a workgroup -> patch permutation for the stack kernel
-int shray_debug_set_patch_order(shray_scene *scene, const uint32_t *order, uint32_t count)
-{
-    if (!scene)
-        return SHRAY_ERR_INVALID_ARGUMENT;
-    if (!order || count == 0) {
-        scene->patch_order_count = 0;
-        return SHRAY_OK;
-    }
-    HIP_TRY(scene->patch_order.upload(order, (size_t)count * 4));
-    scene->patch_order_count = count;
-    return SHRAY_OK;
-}
-#endif
 
 int shray_scene_dispatch_order(shray_scene *scene, uint32_t *order_out, uint32_t capacity, uint32_t *count_out)
 {
@@ -1537,6 +1483,45 @@ int shray_selftest_reciprocal(uint64_t *mismatches)
     unsigned long long n = 0;
     HIP_TRY(hipMemcpy(&n, count.p, sizeof(n), hipMemcpyDeviceToHost));
     *mismatches = n;
+    return SHRAY_OK;
+}
+
+int shray_probe_vector_cache(uint32_t records, uint32_t spread, uint32_t visits_per_lane, uint32_t waves, uint64_t lane_mask, int bytes_per_lane,
+                             double *seconds, uint64_t *bytes_loaded)
+{
+    if (!seconds || !bytes_loaded)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "seconds or bytes_loaded is NULL");
+    auto power_of_two = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
+    const uint32_t runs = spread & 0x80000000u;
+    spread &= 0x7fffffffu;
+    if (!power_of_two(records) || !power_of_two(spread) || spread > records || records > (1u << 26) || visits_per_lane == 0 ||
+        visits_per_lane % 8 != 0 || waves == 0 || waves > (1u << 24) ||
+        !(bytes_per_lane == 32 || bytes_per_lane == 16 || bytes_per_lane == 12 || bytes_per_lane == 8 || bytes_per_lane == 4))
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_probe_vector_cache: records and spread are powers of two (spread <= records <= 2^26), "
+                    "visits_per_lane a multiple of 8, waves 1..2^24, bytes_per_lane 32, 16, 12, 8 or 4");
+    DeviceBuffer table, out;
+    HIP_TRY(table.upload(nullptr, (size_t)records * 32));
+    HIP_TRY(out.upload(nullptr, (size_t)waves * 64 * 4));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    float ms = 0.0f;
+    hipError_t e = hipSuccess;
+    for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {      // the first pass warms the caches and the clock
+        (void)hipEventRecord(a, nullptr);
+        e = shray::launch_vector_cache_probe((const float4 *)table.p, records, spread | runs, visits_per_lane, waves, (unsigned long long)lane_mask, bytes_per_lane, (float *)out.p, nullptr);
+        (void)hipEventRecord(b, nullptr);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(b);
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&ms, a, b);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e != hipSuccess)
+        return fail(SHRAY_ERR_DEVICE, "vector-cache probe failed: %s", hipGetErrorString(e));
+    *seconds = (double)ms * 1e-3;
+    *bytes_loaded = (uint64_t)waves * (uint64_t)__builtin_popcountll(lane_mask) * (uint64_t)visits_per_lane * (uint64_t)bytes_per_lane;
     return SHRAY_OK;
 }
 

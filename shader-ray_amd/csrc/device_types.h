@@ -77,7 +77,6 @@ struct FrameView {
     // multi-sample frames in the convergent batch kernel: a pixel's samples run in 2^sample_log_x x 2^sample_log_y
     // neighbouring lanes of a wave (uniform_driver.h); 0, 0 = one lane per pixel
     uint32_t sample_log_x, sample_log_y;
-    const uint32_t *patch_order; // optional: workgroup b renders patch patch_order[b] (a permutation); nullptr = identity
     // dispatch order of the convergent batch kernels (capi.hip: DispatchOrder): the launch's k-th patch slot renders patch
     // dispatch_order[k] (nullptr = k), and every wave leaves how long it ran in dispatch_cost[patch] (nullptr = not asked)
     const uint32_t *dispatch_order;
@@ -86,9 +85,6 @@ struct FrameView {
 
 // SHRAY_DISPATCH_ORDER (1): heaviest patches first in the convergent batch kernels (capi.hip: DispatchOrder); 0 compiles
 // the waves' part of it out (A/B builds)
-#ifndef SHRAY_DISPATCH_ORDER
-#define SHRAY_DISPATCH_ORDER 1
-#endif
 
 struct DeviceCounters {
     unsigned long long node_visits, leaf_visits, triangle_tests, shaded_hits, env_lookups, traversals, bad_hits, samples;

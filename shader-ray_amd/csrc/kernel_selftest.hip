@@ -87,4 +87,75 @@ hipError_t launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_
     return hipGetLastError();
 }
 
+
+// shray_probe_vector_cache: what a CU's vector L1 delivers to the access pattern of a node visit.  One-wave workgroups,
+// every lane reads whole 32-byte records (two global_load_dwordx4, as load_packed_node does) of a table of `records`
+// records; the 64 lanes of a wave-instruction pick theirs among `spread` consecutive records around a base that changes
+// pseudo-randomly from visit to visit (spread 1: the wave at one node; 64: every lane elsewhere), eight visits in flight
+// per wave.  Nothing else is done with the data than a sum, so the rate is the memory pipeline's, not the arithmetic's.
+// BYTES: what a lane reads of its record per visit: 32 = the node's two 16-byte loads; 16, 12, 8, 4 = one load of that width
+template <int BYTES>
+__global__ void __launch_bounds__(64, 7) vector_cache_probe_kernel(const float4 *__restrict__ table, uint32_t record_mask, uint32_t spread_mask,
+                                                                   uint32_t visits, unsigned long long lanes, float *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t base = (blockIdx.x * 2654435761u) ^ 0x9e3779b9u;
+    // this lane's place inside the spread: pseudo-random, or (bit 31 of spread_mask) runs of neighbouring lanes together
+    const bool runs = (spread_mask >> 31) != 0u;
+    spread_mask &= 0x7fffffffu;
+    const uint32_t mine = runs ? (lane * (spread_mask + 1u)) >> 6 : (lane * 0x61c88647u) >> 7;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    if (!((lanes >> lane) & 1ull))
+        visits = 0;      // only the lanes of the mask take part
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef f3 __attribute__((aligned(4), may_alias)) packed_f3;
+    for (uint32_t v = 0; v < visits; v += 8u) {
+        float4 lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            base = base * 1664525u + 1013904223u;        // uniform over the wave (a scalar sequence)
+            const uint32_t record = ((base >> 9) + (mine & spread_mask)) & record_mask;
+            const char *p = reinterpret_cast<const char *>(table) + (record << 5);
+            lo[k] = hi[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (BYTES >= 16)
+                lo[k] = *reinterpret_cast<const float4 *>(p);
+            if (BYTES == 32)
+                hi[k] = *reinterpret_cast<const float4 *>(p + 16);
+            if (BYTES == 12) {
+                const f3 w = *reinterpret_cast<const packed_f3 *>(p);
+                lo[k] = make_float4(w.x, w.y, w.z, 0.0f);
+            }
+            if (BYTES == 8) {
+                const float2 w = *reinterpret_cast<const float2 *>(p);
+                lo[k] = make_float4(w.x, w.y, 0.0f, 0.0f);
+            }
+            if (BYTES == 4)
+                lo[k].x = *reinterpret_cast<const float *>(p);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            acc0 += lo[k].x + hi[k].w + lo[k].y;
+            acc1 += lo[k].w + hi[k].x + lo[k].z;
+        }
+    }
+    out[blockIdx.x * 64u + lane] = acc0 + acc1;
+}
+
+hipError_t launch_vector_cache_probe(const float4 *table, uint32_t records, uint32_t spread, uint32_t visits, uint32_t waves, unsigned long long lanes,
+                                     int bytes_per_lane, float *out, hipStream_t stream)
+{
+    const uint32_t spread_arg = ((spread & 0x7fffffffu) - 1u) | (spread & 0x80000000u);
+#define SHRAY_PROBE(B) hipLaunchKernelGGL(vector_cache_probe_kernel<B>, dim3(waves), dim3(64), 0, stream, table, records - 1u, spread_arg, visits, lanes, out)
+    switch (bytes_per_lane) {
+    case 32: SHRAY_PROBE(32); break;
+    case 16: SHRAY_PROBE(16); break;
+    case 12: SHRAY_PROBE(12); break;
+    case 8: SHRAY_PROBE(8); break;
+    case 4: SHRAY_PROBE(4); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef SHRAY_PROBE
+    return hipGetLastError();
+}
+
 }   // namespace shray

@@ -1,0 +1,127 @@
+// kernel_stack_common.h -- what the translation units of kernel id 0 share (kernel_stack*.hip): block sizes, the
+// occupancy each class of instance is compiled for, the body of the batch kernels, and the shape of a batch launch.
+// The instances are spread over three translation units so that an edit of the traversal does not cost one 45-second
+// compile on one core: kernel_stack_batch.hip (the timed batch instances), kernel_stack_tally.hip (their tallying twins
+// and the pair traversal), kernel_stack.hip (one frame per launch: the counting twins and the shader's debug views).
+//
+// LDS: BLOCK * stack_levels * 4 bytes of dynamic shared memory (+ 64 bytes per wave for the dealt leaf stage);
+// stack_levels is the deepest stack the tree can ask for (computed at scene creation): 3.9 KB per wave for the
+// bunny-class tree (15 levels), 6.6 KB for the 1M-triangle tree (26 levels: 24 waves per CU).
+#pragma once
+
+#include "launch.h"
+#include "stack_traversal.h"
+#include "uniform_driver.h"
+
+namespace shray {
+
+constexpr int kBlock = 256;
+// the convergent batch instances (every timed launch) are one-wave workgroups: a wave tile's LDS and wave slot are
+// released when THAT wave ends instead of when the slowest wave of its 16x16 patch does
+constexpr int kBatchBlock = 64;
+
+// Waves per SIMD the register allocator must leave room for, per class of instance (-D overrides them for A/B builds:
+// `make variant`).  Measured: profiles/r02/leaf_stage_ab.txt, profiles/r03/dealt_occupancy_ab2.txt, profiles/r04/occupancy_ab.txt.
+#ifndef SHRAY_MIN_WAVES
+#define SHRAY_MIN_WAVES 7                 // zero-diffuse instances with the plain leaf loop (<= 72 registers)
+#endif
+#ifndef SHRAY_MIN_WAVES_DEALT
+#define SHRAY_MIN_WAVES_DEALT 6           // dealt leaf stage, one sample, one frame per launch: a second ray's worth of values (<= 80)
+#endif
+#ifndef SHRAY_MIN_WAVES_DEALT_DENSE
+#define SHRAY_MIN_WAVES_DEALT_DENSE 7     // ... several frames per launch, the throughput form (72 registers, 28 B of scratch outside the
+#endif                                    // loops): 9,369 / 9,450 / 9,247 Mrays/s at 8 / 7 / 6 (round 4)
+#ifndef SHRAY_MIN_WAVES_DEALT_MULTI
+#define SHRAY_MIN_WAVES_DEALT_MULTI 8     // ... multi-sample (the divergent scenes are latency-bound, every wave is worth its spills:
+#endif                                    // the 1M-triangle scene at 4 spp 2.56 / 2.68 / 2.90 ms at 8 / 7 / 6, round 4)
+#ifndef SHRAY_MIN_WAVES_GENERAL
+#define SHRAY_MIN_WAVES_GENERAL 5         // diffuse / shadow-ray instances with the dealt stage: more state, one wave fewer
+#endif
+#ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN
+#define SHRAY_MIN_WAVES_GENERAL_PLAIN 6   // ... with the plain leaf loop (cache-resident scenes: plaster 8 spp 2.57 -> 2.42 ms, round 2)
+#endif
+#ifndef SHRAY_MIN_WAVES_PAIR
+#define SHRAY_MIN_WAVES_PAIR 6
+#endif
+#ifndef SHRAY_MIN_WAVES_PAIR_GENERAL
+#define SHRAY_MIN_WAVES_PAIR_GENERAL 5
+#endif
+
+constexpr int min_waves(bool metal, bool deal, bool one_sample = true)
+{
+    return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES)
+                 : (deal ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_PLAIN);
+}
+
+inline bool one_sample(const FrameView &fr) { return fr.spp == 1; }
+inline bool metal(const FrameView &fr)
+{
+    return !(fr.diffuse_color[0] > 0.0f && fr.diffuse_color[1] > 0.0f && fr.diffuse_color[2] > 0.0f);
+}
+inline bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
+
+inline size_t stack_lds_bytes(int stack_levels, int block = kBlock)
+{
+    // stack columns + the dealt leaf stage's id tables (64 bytes per wave)
+    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)block;
+}
+
+template <bool DEAL, int BLOCK = kBlock, bool PAIR = false>
+__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR> make_traversal(uint32_t *lds, int stack_levels)
+{
+    StackTraversal<BLOCK, DEAL, PAIR> trav;
+    trav.stack = lds + threadIdx.x;
+    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x & ~63u);
+    return trav;
+}
+
+// The body of every convergent batch kernel: one-wave workgroups, four (times the lanes per pixel of a multi-sample
+// frame) per 16x16 patch.
+// DEAL: the dealt leaf stage (wave_traversal.h) instead of the plain leaf loop.
+// TALLY: 0 = the timed kernels; 1 = the same form with per-ray work tallies (what the timed form does); 2 = tallies of
+// the reference's walk (one lane per pixel, every shadow ray to its end) -- the counting twin of the pair traversal.
+// PAIR: both children of a node per turn (wave_traversal.h).  ORDERED: the launch reads a dispatch order (capi.hip).
+template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR, bool ORDERED = false>
+__device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,
+                                                 int stack_levels, int frame_count_arg, DeviceCounters *counters)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR>;
+    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR>(lds_stack, stack_levels);
+    if (ONE_SAMPLE)
+        trav.keep_dealt = SHRAY_KEEP_WALKING_DEALT_ONE;
+    // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
+    // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
+    // start when the launch is half over (what a lone launch, or the last of a run, then waits for)
+    const unsigned int frame_count = gridDim.y == 1 ? (unsigned int)frame_count_arg : 1u;
+    unsigned int frame = blockIdx.y, block_index = blockIdx.x;
+    if (frame_count > 1u) {
+        const FrameView &f0 = frames[0];
+        const unsigned int log_waves = 2u + (ONE_SAMPLE ? 0u : f0.sample_log_x + f0.sample_log_y);
+        const unsigned int b = blockIdx.x, k = b >> 3, rest = k >> log_waves;
+        frame = rest % frame_count;
+        block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
+    }
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1, ORDERED>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
+                                                                               block_index);
+}
+
+// The shape of one batch launch (kernel_stack.hip: launch_stack_batch works it out) and the choices that select an instance.
+struct BatchLaunch {
+    dim3 grid, block;
+    size_t lds_bytes;
+    hipStream_t stream;
+    const FrameView *d_frames;
+    float4 *out;
+    size_t frame_stride;
+    int stack_levels, count;
+    bool one, metallic, deal, dense, ordered;   // one sample per pixel; every frame zero-diffuse; dealt leaf stage; the
+                                                // throughput form's seven-wave dealing instance; reads a dispatch order
+};
+// kernel_stack_batch.hip: the timed instances;  kernel_stack_tally.hip: the tallying twins, the pair traversal (timed and
+// tallying: `tally` == nullptr selects the timed form; full_walk: the reference's walk instead of the timed form's)
+void launch_stack_batch_timed(const SceneView &sc, const BatchLaunch &b);
+void launch_stack_batch_tally(const SceneView &sc, const BatchLaunch &b, DeviceCounters *tally);
+void launch_stack_batch_pair(const SceneView &sc, const BatchLaunch &b, DeviceCounters *tally, bool full_walk);
+
+}   // namespace shray

@@ -65,6 +65,10 @@ hipError_t launch_assemble_tiles(const float *gathered, float4 *out, int world, 
 hipError_t launch_division_selftest(unsigned long long pairs, unsigned long long seed,
                                     unsigned long long *mismatches, hipStream_t stream);
 
+// the memory-pipeline probe behind shray_probe_vector_cache (kernel_selftest.hip); records and spread are powers of two
+hipError_t launch_vector_cache_probe(const float4 *table, uint32_t records, uint32_t spread, uint32_t visits, uint32_t waves, unsigned long long lanes,
+                                     int bytes_per_lane, float *out, hipStream_t stream);
+
 // reciprocal_in_range (exact_div.h) against 1.0f / x on every float of its domain; *mismatches receives the count.
 hipError_t launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t stream);
 

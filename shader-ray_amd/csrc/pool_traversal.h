@@ -114,7 +114,7 @@ struct PoolTraversal {
                     float4 *slot = reinterpret_cast<float4 *>(xbuf) + 5u * rank;
                     slot[0] = make_float4(t.P.x, t.P.y, t.P.z, t.D.x);
                     slot[1] = make_float4(t.D.y, t.D.z, t.Y.x, t.Y.y);
-                    slot[2] = make_float4(t.Y.z, t.YL.x, t.YL.y, t.YL.z);
+                    slot[2] = make_float4(t.Y.z, 0.0f, 0.0f, 0.0f);
                     slot[3] = make_float4(t.hit.t, t.hit.which, t.hit.bu, t.hit.bv);
                     slot[4] = make_float4(__uint_as_float(t.node), __uint_as_float((uint32_t)(t.top - (stack + col))), __uint_as_float((uint32_t)t.left),
                                           __uint_as_float(col | (t.divide ? 0x80000000u : 0u)));
@@ -132,7 +132,6 @@ struct PoolTraversal {
                         t.P = mk(s0.x, s0.y, s0.z);
                         t.D = mk(s0.w, s1.x, s1.y);
                         t.Y = mk(s1.z, s1.w, s2.x);
-                        t.YL = mk(s2.y, s2.z, s2.w);
                         t.hit = Hit{s3.x, s3.y, s3.z, s3.w};
                         t.node = __float_as_uint(s4.x);
                         t.left = (int)__float_as_uint(s4.z);

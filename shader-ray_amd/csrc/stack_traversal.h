@@ -20,9 +20,9 @@
 namespace shray {
 
 // The node loop yields to the leaf stage (when lanes are parked) once fewer than a threshold of lanes
-// are still walking.  SHRAY_RELATIVE_KEEP: the threshold is SHRAY_KEEP_WALKING / 64 of the lanes still
-// in this traversal (at least SHRAY_KEEP_FLOOR) -- a wave with eight live lanes should not leave the node
-// loop after every visit; otherwise it is SHRAY_KEEP_WALKING lanes.  Swept in profiles/variant_probe3.sh.
+// are still walking: SHRAY_KEEP_WALKING / 64 of the lanes still in this traversal (at least SHRAY_KEEP_FLOOR)
+// -- a wave with eight live lanes should not leave the node loop after every visit.  Numeric knobs, -D overrides
+// them for A/B builds (round 2 sweeps: profiles/EXPERIMENTS.md R2.7).
 #ifndef SHRAY_KEEP_WALKING
 #define SHRAY_KEEP_WALKING 36
 #endif
@@ -38,9 +38,6 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #ifndef SHRAY_KEEP_WALKING_DEALT_ONE
 #define SHRAY_KEEP_WALKING_DEALT_ONE 64
 #endif
-#ifndef SHRAY_RELATIVE_KEEP
-#define SHRAY_RELATIVE_KEEP 1
-#endif
 #ifndef SHRAY_KEEP_FLOOR
 #define SHRAY_KEEP_FLOOR 2
 #endif
@@ -51,7 +48,6 @@ struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
     uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
-    const float4 *top = nullptr;   // LDS copy of the first SHRAY_LDS_TOP packed nodes (experiment, else unused)
     int keep_dealt = kStackKeepWalkingDealt;   // a constant of the instance (kernel_stack.hip sets it before the first traversal)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -109,22 +105,18 @@ struct StackTraversal {
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
-#if SHRAY_RELATIVE_KEEP
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
-            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((SHRAY_DEAL_LEAVES && DEAL && CONVERGED) ? keep_dealt : kStackKeepWalking) + 32) >> 6);
+            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((DEAL && CONVERGED) ? keep_dealt : kStackKeepWalking) + 32) >> 6);
             if (PAIR) {
                 inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);
             } else
-                inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG, top);
-#else
-            inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, kStackKeepWalking, false SHRAY_DIAG_ARG);
-#endif
+                inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
 #ifdef SHRAY_DIAGNOSTICS
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
-            if (SHRAY_DEAL_LEAVES && DEAL && CONVERGED)
+            if (DEAL && CONVERGED)
                 leaf_stage_dealt<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             else
                 leaf_stage<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);

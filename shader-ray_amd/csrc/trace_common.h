@@ -22,9 +22,6 @@
 
 // 0: the convergent batch instances run 256-thread workgroups (one 16x16 patch); 1: one-wave workgroups (one 8x8 tile),
 // tiles of a patch on consecutive workgroup ids; 2: one-wave workgroups, the four tiles of a patch on one XCD
-#ifndef SHRAY_WAVE_BLOCKS
-#define SHRAY_WAVE_BLOCKS 2
-#endif
 
 namespace shray {
 
@@ -450,7 +447,7 @@ template <class Traversal, bool COUNT, bool DIFF = false, bool ONE_SAMPLE = fals
 __device__ __forceinline__ void trace_pixels(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                              DeviceCounters *counters, Traversal &trav)
 {
-    const unsigned int patch = fr.patch_order ? fr.patch_order[blockIdx.x] : blockIdx.x;
+    const unsigned int patch = blockIdx.x;
 #ifdef SHRAY_DIAGNOSTICS
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // diagnostic build only (profiles/timeline.py): per-wave residency stamps, written to a

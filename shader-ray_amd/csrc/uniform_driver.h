@@ -22,9 +22,6 @@
 namespace shray {
 
 // shadow rays stop at their first hit (stack_traversal.h: closest<COUNT, ANY_HIT>); 0 = walk them to the end
-#ifndef SHRAY_SHADOW_ANY_HIT
-#define SHRAY_SHADOW_ANY_HIT 1
-#endif
 
 // COUNT: tally per-ray work.  The counting twins walk every shadow ray to its end and run one lane per pixel, so that
 // their tallies equal the reference's full traversals (the oracle's); with TIMED_FORM they keep the timed instances'
@@ -56,7 +53,6 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     unsigned int sub = 0, base_lane = threadIdx.x & 63u;
     // a 256-thread workgroup is a 16x16 patch (four 8x8 wave tiles); a 64-thread workgroup is one of those tiles
     if (Traversal::block_size == 64) {
-#if SHRAY_WAVE_BLOCKS == 2
         // workgroups go to the eight XCDs round robin: keep the waves of a patch (four, or 4 G with sample lanes) on one
         // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
         // waves leave here.
@@ -73,10 +69,6 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             if (fr.dispatch_cost)
                 cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
         }
-#else
-        const unsigned int log_waves = 2u + log_gx + log_gy;
-        const unsigned int patch = block_index >> log_waves, wave = block_index & ((1u << log_waves) - 1u);
-#endif
         // the patch as (16 gx) x (16 gy) lane positions, cut into 8x8 wave tiles: position (vx, vy) is sample
         // (vy % gy) * gx + vx % gx of pixel (vx / gx, vy / gy)
         const unsigned int lane = threadIdx.x, tiles_across = 2u << log_gx;
@@ -146,7 +138,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                 bool lit = true;
                 if (fr.cast_shadows) {                            // uniform
                     Hit shadow{kFar, -1.0f, 0.0f, 0.0f};
-                    pool.template closest<COUNT, SHRAY_SHADOW_ANY_HIT != 0, TIMED_FORM>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
+                    pool.template closest<COUNT, true, TIMED_FORM>(sc, fr, shade, xform(fr.object_matrix, P2, 1.0f),
                                                  xform(fr.object_normal_matrix, light, 0.0f), shadow, rc);
                     lit = shadow.t >= kFar;
                 }

@@ -34,31 +34,8 @@ namespace shray {
 // LT_LEAF it is "parked" -- served by the next leaf stage.  Parked states are even.
 enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 
-// experiment: stage the first SHRAY_LDS_TOP packed nodes in LDS (0 = off, the shipped form)
-#ifndef SHRAY_LDS_TOP
-#define SHRAY_LDS_TOP 0
-#endif
-// round 3: the stack position moved by an add tied to its register (top_move), the leaf's count word parked as it is
-// and clamped once per leaf stage (parked_count): five vector instructions fewer per node turn in the ISA
-#ifndef SHRAY_TIED_TOP
-#define SHRAY_TIED_TOP 1
-#endif
-#ifndef SHRAY_TRIANGLE_WORDS
-#define SHRAY_TRIANGLE_WORDS 1
-#endif
-#ifndef SHRAY_TIED_ACCEPT
-#define SHRAY_TIED_ACCEPT 1
-#endif
-// experiment (off): the dealt stage's combine with DPP moves instead of ds_bpermute -- no faster (profiles/EXPERIMENTS.md R3.8)
-#ifndef SHRAY_DPP_COMBINE
-#define SHRAY_DPP_COMBINE 0
-#endif
-#ifndef SHRAY_BUFFER_LOADS
-#define SHRAY_BUFFER_LOADS 0
-#endif
-#ifndef SHRAY_PARK_RAW
-#define SHRAY_PARK_RAW 1
-#endif
+// Variants that were built, measured and removed (LDS staging of the top of the tree, MUBUF loads, a DPP combine in the
+// dealt stage, untied register moves, ...): profiles/EXPERIMENTS.md, with their numbers.
 // node visits per lane between two evaluations of inner_stage's exit tests (fewer instructions against more
 // registers; three measured best in round 2, profiles/r02/leaf_stage_ab.txt)
 #ifndef SHRAY_NODE_TURNS
@@ -87,7 +64,8 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 #endif
 
 struct LaneTraversal {
-    V3 P, D, Y, YL;           // object-space ray, reciprocal direction RN(1/D) and its residual (exact_div.h)
+    V3 P, D, Y;               // object-space ray and its reciprocal direction RN(1/D) (exact_div.h); the residual of the
+                              // reciprocal is recomputed where the exact quotients are needed (slab_range: a rare branch)
     bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
     uint32_t positive_dir;
     Hit hit;
@@ -108,13 +86,9 @@ typedef __attribute__((address_space(3))) uint32_t lds_word;
 template <int BYTES>
 __device__ __forceinline__ void top_move(uint32_t *&top)
 {
-#if SHRAY_TIED_TOP
     lds_word *p = (lds_word *)top;
     asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(p) : "i"((unsigned int)BYTES));
     top = (uint32_t *)p;
-#else
-    top += BYTES / 4;
-#endif
 }
 
 // group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
@@ -136,7 +110,6 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
             t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     }
 #endif
-    t.YL = mk(reciprocal_residual(D.x, t.Y.x), reciprocal_residual(D.y, t.Y.y), reciprocal_residual(D.z, t.Y.z));
     t.fx = D.x >= 0.0f;
     t.fy = D.y >= 0.0f;
     t.fz = D.z >= 0.0f;
@@ -189,19 +162,31 @@ __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
 // triangle byte offsets stay far below 2^32.)
 __device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
 {
-#if SHRAY_BUFFER_LOADS
-    // experiment: the same two loads as MUBUF instructions (a buffer descriptor in four scalar registers + the offset)
-    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(static_cast<const void *>(sc.packed_nodes)), 0, -1, 0x00020000);
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(node << 5), 0, 0);
-    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(node << 5) + 16, 0, 0);
-    lo = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-    hi = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-#else
     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + (node << 5));
     lo = p[0];
     hi = p[1];
-#endif
+}
+
+// The same for the lanes of a wave that are executing, when they are all at ONE node (the top of the tree, coherent primary
+// rays: 51 % of the headline's wave-visits, profiles/r04/distinct_nodes_per_wave_visit.txt).  A CU's vector memory
+// pipeline -- one per CU, shared by its four SIMDs -- spends about 14 cycles on a 16-byte-per-lane instruction whatever its
+// lanes read, even with one lane active (profiles/r04/vector_cache_probe.json), and that pipeline is what bounds the node
+// loop; a node every lane wants is fetched once, through the scalar cache, and copied into the
+// lanes' registers (eight moves).  +3.1 % on the headline, +2.5 ... +3.6 % on configs 3-5 (profiles/r04/scalar_nodes_ab.txt).
+// Serving SOME lanes that way and the others with the vector load -- one, two, three or four groups, one after the other --
+// puts two dependent fetches into one visit and is 15-30 % slower (same file): only the all-at-one-node case is taken.
+__device__ __forceinline__ void load_packed_node_shared(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
+{
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+    if (wave_ballot(node != first) == 0ull) {
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(4))) const f8 constant_f8;
+        const f8 v = *reinterpret_cast<constant_f8 *>(reinterpret_cast<uintptr_t>(sc.packed_nodes) + ((uintptr_t)first << 5));
+        lo = make_float4(v[0], v[1], v[2], v[3]);
+        hi = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        load_packed_node(sc, node, lo, hi);
+    }
 }
 
 // range_intersect_box of the node's box against [0, 1e8] (fs:200-217, :272-275): the entry plane is the box's low
@@ -212,14 +197,75 @@ __device__ __forceinline__ void slab_range(const LaneTraversal &t, const float4 
     const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
     const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
     // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
-    r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, t.YL.y)),
-               div_by_constant4(ez, t.D.z, t.Y.z, t.YL.z));
-    r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, t.YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, t.YL.y)),
-               div_by_constant4(xz, t.D.z, t.Y.z, t.YL.z));
+    const V3 YL = mk(reciprocal_residual(t.D.x, t.Y.x), reciprocal_residual(t.D.y, t.Y.y), reciprocal_residual(t.D.z, t.Y.z));
+    r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, YL.y)),
+               div_by_constant4(ez, t.D.z, t.Y.z, YL.z));
+    r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, YL.y)),
+               div_by_constant4(xz, t.D.z, t.Y.z, YL.z));
     if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
         r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
         r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
     }
+}
+
+// The visit's decision without the exact quotients (round 4).  fs:400 asks `!(r0 >= r1) && r0 < hit.t` of the correctly
+// rounded quotients; a quotient's one-multiplication approximation q~ = RN(a * RN(1 / b)) differs from RN(a / b) by less
+// than 3 * 2^-24 of it and has its sign, so r0~ = max(0, q~...) and r1~ = min(1e8, q~...) are within 2^-22 (relative) of
+// r0 and r1, and
+//      r0~ (1 + 2^-20) <  min(r1~, hit.t)   =>  the box is entered       (r0 <= r0~ (1 + 2^-22) < r1~ (1 - 2^-22) <= r1, < hit.t)
+//      r0~ (1 - 2^-20) >= min(r1~, hit.t)   =>  it is not                (r0 >= r0~ (1 - 2^-22) >= r1 or >= hit.t; r1~ <= 0: r1 <= 0 <= r0)
+// decide all but about one visit in 10^5 exactly as the quotients would: 22 + 5 vector instructions instead of 40.  A lane
+// that neither test decides -- or whose operands are outside exact_div.h's ranges (t.divide: also a lane whose hit.t is NaN,
+// leaf_finish) -- evaluates slab_range in a branch the wave skips.  What a lane parks for its leaf's triangle tests is the
+// pair of bounds lo0 = r0~ (1 - 2^-20) <= r0 and hi1 = r1~ (1 + 2^-20) >= r1 (or r0, r1 themselves from that branch):
+// a candidate outside [lo0, hi1] is outside [r0, r1]; one inside that is about to be ACCEPTED is looked at again
+// (leaf_range_check: within 2^-19 of an end the leaf's exact range is computed and decides, fs:327-331).
+// Frames and work counters stay bit-identical to the reference's divisions (the GPU parity suite).
+constexpr float kBandUp = 1.0f + 0x1p-20f, kBandDown = 1.0f - 0x1p-20f;       // node test, parked bounds
+constexpr float kCheckUp = 1.0f + 0x1p-19f, kCheckDown = 1.0f - 0x1p-19f;     // leaf_range_check
+
+__device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
+{
+    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
+    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    r0 = fmaxf(fmaxf(fmaxf(0.0f, ex * t.Y.x), ey * t.Y.y), ez * t.Y.z);
+    r1 = fminf(fminf(fminf(kRangeMax, xx * t.Y.x), xy * t.Y.y), xz * t.Y.z);
+}
+
+// The leaf's exact clipped range (fs:406: the range the leaf's box test left), from the leaf's own record: t.node is
+// still the leaf while a lane is parked (not in the pair traversal, which parks exact ranges and never asks).
+__device__ __forceinline__ void exact_leaf_range(const SceneView &sc, const LaneTraversal &t, float &e0, float &e1)
+{
+    float4 lo, hi;
+    load_packed_node(sc, t.node, lo, hi);
+    slab_range(t, lo, hi, e0, e1);
+}
+
+// A candidate distance that passed `d < leaf_r0 || d > leaf_r1` against the parked bounds and is about to be accepted:
+// true if it is so close to an end that the exact range could still reject it.
+__device__ __forceinline__ bool near_range_end(float d, float lo0, float hi1) { return d * kCheckDown < lo0 || d * kCheckUp > hi1; }
+
+// fs:400's decision for one visit; r0 = a lower bound of the box's entry distance, r1 = an approximation of its exit
+// distance within 2^-22 (or both exact, from the branch): see above.
+__device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
+{
+    slab_range_fast(t, lo, hi, r0, r1);
+    float below;   // min(r1~, hit.t): one bare v_min_f32 (a NaN hit.t makes its lane divide, so the branch below decides it)
+    asm("v_min_f32 %0, %1, %2" : "=v"(below) : "v"(r1), "v"(t.hit.t));
+    const float lo0 = r0 * kBandDown;
+    bool enter = r0 * kBandUp < below;
+    const bool unsure = !(enter || lo0 >= below) || t.divide;
+    r0 = lo0;
+#ifndef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes
+    if (__builtin_expect(wave_ballot(unsure) != 0ull, 0)) {
+        asm volatile("; a visit the bounds do not decide: the exact quotients" ::: "memory");   // keeps this a branch
+        if (unsure) {
+            slab_range(t, lo, hi, r0, r1);
+            enter = !(r0 >= r1) && (r0 < t.hit.t);
+        }
+    }
+#endif
+    return enter;
 }
 
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
@@ -237,19 +283,15 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
         rc.leaf_visits++;   // the reference fetches (start, count) before the box test, fs:263-267
 
     float r0, r1;
-    slab_range(t, lo, hi, r0, r1);
-
-    if (!(r0 >= r1) && (r0 < t.hit.t)) {
+    const bool enter = visit_decision(t, lo, hi, r0, r1);
+    if (enter) {
         if (b & kLeafFlag) {
-#if SHRAY_PARK_RAW
+            // (the leaf's upper bound; a lane that took the exact branch parks a bound 2^-20 above its r1: still a bound)
+            r1 = r1 * kBandUp;
             // the leaf's count word is parked as it is (flag bit and all); the leaf stages clamp it to the leaf cap
             // once per stage (parked_count) instead of every visit masking, clamping and testing it
             const uint32_t count = b;
             if (b != kLeafFlag && t.leaf_cap != 0u) {
-#else
-            const uint32_t count = min(b & ~kLeafFlag, t.leaf_cap);
-            if (count > 0) {
-#endif
                 // the parked leaf's four fields are written HERE only.  As plain assignments they become loop-carried
                 // phis that the compiler resolves with eight register copies on the inner-node path (the common one);
                 // a move whose destination is tied to the old value keeps each field in one register on every path.
@@ -317,19 +359,18 @@ __device__ __forceinline__ bool triangle_distance(const LaneTraversal &t, const 
     s.T = t.P - v0;
     s.Q = cross3(s.T, e0);
     s.dist = -dot3(e1, s.Q) * s.inv_det;
-#if SHRAY_TRIANGLE_WORDS
     // `d > hit.t || d > r1` is `d > min(hit.t, r1)` whatever is NaN (the hardware minimum returns the other operand, and a
     // comparison with NaN is false either way); the compiler makes the same fold but canonicalises both operands first
     // (two v_max x, x per test).  One bare v_min_f32:
     float upper;
     asm("v_min_f32 %0, %1, %2" : "=v"(upper) : "v"(t.hit.t), "v"(t.leaf_r1));
     return !(s.dist > upper || s.dist < t.leaf_r0);
-#else
-    return !(s.dist > t.hit.t || s.dist < t.leaf_r0 || s.dist > t.leaf_r1);
-#endif
 }
 // Second half, fs:333-346: the barycentric tests and the store.
-__device__ __forceinline__ void triangle_barycentrics(LaneTraversal &t, uint32_t which, const TriangleSetup &s)
+// BOUNDS: the lane parked bounds of its leaf's range, not the range (lane_visit_loaded): a candidate that has passed
+// everything else and lies within 2^-19 of an end is held against the exact range before it is stored.
+template <bool BOUNDS>
+__device__ __forceinline__ void triangle_barycentrics(const SceneView &sc, LaneTraversal &t, uint32_t which, const TriangleSetup &s)
 {
     const float u = dot3(s.T, s.M) * s.inv_det;
     if (u < 0.0f || u > 1.0f)
@@ -337,6 +378,18 @@ __device__ __forceinline__ void triangle_barycentrics(LaneTraversal &t, uint32_t
     const float w = dot3(t.D, s.Q) * s.inv_det;
     if (w < 0.0f || u + w > 1.0f)
         return;
+    if (BOUNDS) {
+        const bool near_end = near_range_end(s.dist, t.leaf_r0, t.leaf_r1);
+        if (__builtin_expect(wave_ballot(near_end) != 0ull, 0)) {
+            asm volatile("; a candidate at an end of its leaf's range: the exact range" ::: "memory");   // keeps this a branch
+            if (near_end) {
+                float e0, e1;
+                exact_leaf_range(sc, t, e0, e1);
+                if (s.dist < e0 || s.dist > e1)
+                    return;                       // fs:329-331
+            }
+        }
+    }
     t.hit.which = (float)which;
     t.hit.t = s.dist;
     t.hit.bu = u;
@@ -344,15 +397,15 @@ __device__ __forceinline__ void triangle_barycentrics(LaneTraversal &t, uint32_t
 }
 
 // triangle_intersect of triangle `which` (its three 16-byte words) for a parked lane
-template <bool COUNT>
-__device__ __forceinline__ void lane_test_triangle_loaded(LaneTraversal &t, uint32_t which, RayCounters &rc,
+template <bool COUNT, bool BOUNDS>
+__device__ __forceinline__ void lane_test_triangle_loaded(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc,
                                                           const float4 q0, const float4 q1, const float4 q2)
 {
     if (COUNT)
         rc.triangle_tests++;
     TriangleSetup s;
     if (triangle_distance(t, q0, q1, q2, s))
-        triangle_barycentrics(t, which, s);
+        triangle_barycentrics<BOUNDS>(sc, t, which, s);
 }
 
 // The nine floats of a packed triangle, fetched as three 12-byte loads issued back to back and handed on as the
@@ -365,17 +418,6 @@ struct PackedF3 {
 __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
 {
     // base + 32-bit byte offset, as for the nodes
-#if SHRAY_BUFFER_LOADS
-    typedef unsigned int v3u __attribute__((ext_vector_type(3)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(static_cast<const void *>(sc.packed_tris)), 0, -1, 0x00020000);
-    const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u), 0, 0);
-    const v3u b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u) + 12, 0, 0);
-    const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(index * 36u) + 24, 0, 0);
-    q0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(b.x));
-    q1 = make_float4(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(c.x), __uint_as_float(c.y));
-    q2 = make_float4(__uint_as_float(c.z), 0.0f, 0.0f, 0.0f);
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x));
-#elif SHRAY_TRIANGLE_WORDS
     // 36 bytes as 16 + 16 + 4 (what the back end makes of three 12-byte loads anyway), pinned as the register tuples the
     // loads fill: pinned component by component, every test began with five or six moves out of those tuples
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -387,31 +429,14 @@ __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32
     q0 = make_float4(a.x, a.y, a.z, a.w);
     q1 = make_float4(b.x, b.y, b.z, b.w);
     q2 = make_float4(c, 0.0f, 0.0f, 0.0f);
-#else
-    const PackedF3 *p = reinterpret_cast<const PackedF3 *>(reinterpret_cast<const char *>(sc.packed_tris) + index * 36u);
-    const PackedF3 a = p[0], b = p[1], c = p[2];
-    q0 = make_float4(a.x, a.y, a.z, b.x);
-    q1 = make_float4(b.y, b.z, c.x, c.y);
-    q2 = make_float4(c.z, 0.0f, 0.0f, 0.0f);
-    // pin the nine components here: whole loads, nothing deferred past a branch
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x));
-#endif
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void lane_test_triangle(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc)
-{
-    float4 q0, q1, q2;
-    load_packed_triangle(sc, which, q0, q1, q2);
-    lane_test_triangle_loaded<COUNT>(t, which, rc, q0, q1, q2);
-}
 
 // Node loop: lanes whose state is LT_WALK visit nodes until fewer than `keep_walking` of
 // them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM,
-                                            const float4 *lds_top = nullptr)
+                                            uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM)
 {
     for (;;) {
         if (!wave_ballot(state == LT_WALK))
@@ -421,22 +446,8 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
             SHRAY_DIAG_COUNT(0);
             if (state == LT_WALK) {
                 SHRAY_DIAG_T0
-#if SHRAY_LDS_TOP
-                const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.packed_nodes);
-                // experiment (profiles/r02/lds_top_ab.txt): the first SHRAY_LDS_TOP nodes (the top levels, breadth
-                // first) are read from a copy the workgroup staged in LDS
                 float4 lo, hi;
-                if (t.node < (uint32_t)SHRAY_LDS_TOP) {
-                    lo = lds_top[2u * t.node];
-                    hi = lds_top[2u * t.node + 1u];
-                } else {
-                    lo = nodes[2u * t.node];
-                    hi = nodes[2u * t.node + 1u];
-                }
-#else
-                float4 lo, hi;
-                load_packed_node(sc, t.node, lo, hi);
-#endif
+                load_packed_node_shared(sc, t.node, lo, hi);
                 SHRAY_DIAG_WAIT(4);
                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
             }
@@ -457,7 +468,7 @@ __device__ __forceinline__ uint32_t parked_count(uint32_t leaf_count, uint32_t l
 // Leaf stage: every parked lane tests its leaf's triangles in order, then follows its link.
 // PAIR: the lane belongs to the pair traversal (below): "follow the link" is lane_pop.
 // its loop (some lane must be parked) ...
-template <bool COUNT>
+template <bool COUNT, bool BOUNDS>
 __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
 {
 #ifdef SHRAY_DIAGNOSTICS
@@ -485,7 +496,7 @@ __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t,
             SHRAY_DIAG_T0
             load_packed_triangle(sc, t.leaf_first + j, q0, q1, q2);
             SHRAY_DIAG_WAIT(5);
-            lane_test_triangle_loaded<COUNT>(t, t.leaf_first + j, rc, q0, q1, q2);
+            lane_test_triangle_loaded<COUNT, BOUNDS>(sc, t, t.leaf_first + j, rc, q0, q1, q2);
         }
         j++;
     } while (wave_ballot(j < mine));
@@ -500,6 +511,10 @@ __device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &
             state = lane_pop<COUNT, BLOCK>(sc, t, stack, rc);
         return;
     }
+    // a hit distance that is NaN (an unordered candidate was accepted, see leaf_stage_dealt) fails `r0 < hit.t` at every
+    // later visit; the visit's fast test does not look for it: such a lane takes the exact branch from here on
+    if (state == LT_LEAF)
+        t.divide = t.divide || t.hit.t != t.hit.t;
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, false, 0u);
     lane_apply_cap(t, state);
@@ -511,7 +526,7 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
 {
     if (!wave_ballot(state == LT_LEAF))
         return;
-    leaf_loop<COUNT>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+    leaf_loop<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
 }
 
@@ -538,9 +553,6 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
 // outcome no (d, j) ranking reproduces.  A worker that accepts an unordered d raises a flag; if any lane of the
 // wave did, the stage discards the dealt result and runs the plain sequential loop over the untouched parked
 // rays (tests/test_gpu_parity.py::test_nan_candidates_in_a_dealt_leaf).
-#ifndef SHRAY_DEAL_LEAVES
-#define SHRAY_DEAL_LEAVES 1
-#endif
 #ifndef SHRAY_DEAL_MAX_PARKED
 #define SHRAY_DEAL_MAX_PARKED 32   // at most 32: a group is at least two lanes
 #endif
@@ -598,7 +610,7 @@ __device__ __forceinline__ void combine_dpp(float &best_d, float &best_u, float 
 // a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
 // (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its
 // lane number)
-template <bool COUNT>
+template <bool COUNT, bool BOUNDS>
 __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTraversal &t, int state, RayCounters &rc, uint8_t *ids,
                                              unsigned long long parked, int K, float &wd, float &wu, float &ww,
                                              uint32_t &won SHRAY_DIAG_PARAM)
@@ -639,7 +651,6 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
                 rc.triangle_tests++;
             float d, u, w;
             if (triangle_candidate(P, D, r0, r1, q0, q1, q2, d, u, w) && !(d > best_d)) {
-#if SHRAY_TIED_ACCEPT
                 // the worker's best candidate so far is rewritten HERE only, deep inside the test's early-outs: as plain
                 // assignments the four values (and the flag, a lane mask) are copied back and forth at every level of that
                 // nest, ~24 moves and a dozen scalar mask operations per triangle; tied to their registers, none
@@ -648,13 +659,15 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
                              : "+v"(best_d), "+v"(best_u), "+v"(best_w), "+v"(best), "+v"(unordered_flag)
                              : "v"(d), "v"(u), "v"(w), "v"(tri)
                              : "vcc");
-#else
-                best_d = d;
-                best_u = u;
-                best_w = w;
-                best = tri;
-                unordered = unordered || d != d;
-#endif
+                if (BOUNDS) {
+                    // r0, r1 are bounds of the leaf's range (lane_visit_loaded): a candidate within 2^-19 of an end is for the
+                    // exact range to decide -- the stage then runs the sequential loop, which does that (same flag)
+                    float scaled;
+                    asm volatile("v_mul_f32 %1, %4, %2\n\tv_cmp_lt_f32 vcc, %1, %3\n\tv_cndmask_b32 %0, %0, 1, vcc"
+                                 : "+v"(unordered_flag), "=&v"(scaled) : "v"(d), "v"(r0), "s"(kCheckDown) : "vcc");
+                    asm volatile("v_mul_f32 %1, %4, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_cndmask_b32 %0, %0, 1, vcc"
+                                 : "+v"(unordered_flag), "=&v"(scaled) : "v"(d), "v"(r1), "s"(kCheckUp) : "vcc");
+                }
             }
         }
         tri += (uint32_t)G;
@@ -664,19 +677,6 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
     }
     // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
-#if SHRAY_DPP_COMBINE
-    // A group is 2, 4, 8 or 16 neighbouring lanes, i.e. part of one DPP row: its lanes exchange candidates with
-    // data-parallel-primitive moves (one vector instruction each, no LDS round trip): neighbours in a quad, the quad's
-    // halves, the mirror image in a half row, the mirror image in the row.  Every exchange is between two lanes that both
-    // apply the same symmetric rule, so after the last one each lane of the group holds the group's winner.
-    combine_dpp<0xB1>(best_d, best_u, best_w, best);            // quad_perm [1, 0, 3, 2]
-    if (G > 2)
-        combine_dpp<0x4E>(best_d, best_u, best_w, best);        // quad_perm [2, 3, 0, 1]
-    if (G > 4)
-        combine_dpp<0x141>(best_d, best_u, best_w, best);       // row_half_mirror
-    if (G > 8)
-        combine_dpp<0x140>(best_d, best_u, best_w, best);       // row_mirror
-#else
     for (int step = 1; step < G; step <<= 1) {
         const int other = lane ^ step;
         const float od = lane_pull(other, best_d);
@@ -688,7 +688,6 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         best_w = take ? ow : best_w;
         best = take ? ob : best;
     }
-#endif
     // the parked lane collects its group's winner and moves on (fs:416-433)
     const int from = rank << log_g;
     wd = lane_pull(from, best_d);
@@ -705,6 +704,7 @@ template <bool COUNT, int BLOCK, bool PAIR = false>
 __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
                                                  uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
 {
+    constexpr bool BOUNDS = !PAIR;   // the parked leaf range is a pair of bounds (lane_visit_loaded)
     const unsigned long long parked = wave_ballot(state == LT_LEAF);
     if (!parked)
         return;
@@ -713,14 +713,14 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     uint32_t won = 0xffffffffu;
     bool plain = K > SHRAY_DEAL_MAX_PARKED, tallied = false;
     if (!plain) {
-        plain = dealt_search<COUNT>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
+        plain = dealt_search<COUNT, BOUNDS>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
         tallied = true;
     }
     if (plain) {
         if (COUNT && !tallied)
-            leaf_loop<COUNT>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+            leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
         else
-            leaf_loop<false>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+            leaf_loop<false, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     } else if (state == LT_LEAF && won != 0xffffffffu) {
         // the parked lane takes its group's winner
         t.hit.which = (float)won;

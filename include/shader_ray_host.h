@@ -40,8 +40,8 @@ typedef struct shray_host_world_info {
     int32_t leaf_count;
     int32_t max_level;
     int32_t large_leaves;
-    double parse_seconds;
-    double build_seconds;
+    double parse_seconds;        /* file -> triangle_set (parse, shared vertices, normals), centre + extent */
+    double build_seconds;        /* make_bvh */
 } shray_host_world_info;
 
 /* load_world() (world.h:64): parse .trisrc / .obj, centre + extent, make_bvh.

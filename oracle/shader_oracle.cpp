@@ -85,6 +85,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -140,8 +141,14 @@ inline float sr_atan2(float y, float x)
     return r;
 }
 inline float sr_acos(float x) { return sr_atan2(sqrtf((1.0f - x) * (1.0f + x)), x); }
+// pow(x, 5.0) of fs:481.  GLSL leaves pow undefined for x < 0, and the implementations that run the reference evaluate it
+// as exp2(5 log2 x): NaN for a negative base (measured on the driver behind the fixtures: the three pixels of a 1080p
+// frame where an fp16-rounded normal slightly longer than 1 makes the base -1e-8 come out black -- the NaN reaches
+// tonemap_and_gamma's max(0, c - .004), which by GLSL's definition returns 0).  So does this; x^5 for x >= 0 (-0 included).
 inline float sr_pow5(float x)
 {
+    if (x < 0.0f)
+        return std::numeric_limits<float>::quiet_NaN();
     const float x2 = x * x;
     return (x2 * x2) * x;
 }
@@ -262,10 +269,28 @@ struct Ctx {
     const Scene *scene;
     const shray_frame_params *p;
     Counters c;
+    // diagnostics (shray_oracle_set_path_map): what the last trace() did -- see there
+    uint32_t path = 0;
+    int32_t first_triangle = -1;
+    float last_which = -1.0f;
+    bool last_lit = false;
+    float edge_margin = 1.0f;     // the smallest barycentric coordinate of any closest hit of the path (1: no hit)
+    float last_edge_margin = 1.0f;
+    float env_dy = 0.0f;          // D.y of the last environment lookup, before the clamp of sample_environment
 };
 
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
 uint32_t *g_visit_map = nullptr;
+
+// optional per-pixel path planes (tests/pixel_classifier.py: where the frame is discontinuous): for spp == 1 plain frames,
+// path = bit 2i: bounce i hit a triangle, bit 2i + 1: that hit was lit (its shadow ray escaped; only when diffuse > 0),
+// bits 24-27: bounces that hit, bit 30: the iteration-cap marker; first_triangle = the primary ray's triangle or -1
+// edge_margin = the smallest barycentric coordinate of any of the path's hits: a ray that passes within a few 1e-7 of an edge
+// two triangles share can, in another arithmetic, miss both (the test of fs:333-340 is not watertight) or hit the other one
+uint32_t *g_path_map = nullptr;
+int32_t *g_first_triangle_map = nullptr;
+float *g_edge_margin_map = nullptr;
+float *g_env_dy_map = nullptr;   // D.y of the pixel's environment lookup as the shader hands it to acos (|D.y| > 1: undefined there)
 
 // optional per-ray event trace (diagnostics, single-threaded renders only; oracle/tools/wave_sim.cpp reads it):
 // per sample, per traversal: 0xF0 then one byte per node visit = the number of triangle tests that visit ran
@@ -498,9 +523,11 @@ vec3 approximate_diffuse(Ctx &cx, vec3 point, vec3 normal)
         const ray world_shadowray = make_ray(point, light_dir);
         const ray object_shadowray = ray_transform(world_shadowray, p.object_matrix, p.object_normal_matrix);
         group_intersect(cx, cx.scene->tree_root, object_shadowray, make_range(0.0f, 100000000.0f), shadow_hit);
+        cx.last_lit = shadow_hit.t >= infinitely_far;
         if (shadow_hit.t >= infinitely_far)
             diffuse = diffuse + light_diffuse;
     } else {
+        cx.last_lit = true;
         diffuse = diffuse + light_diffuse;
     }
     return diffuse;
@@ -532,6 +559,8 @@ int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3
 
     // shade(), fs:362-377; hit.which >= 0 always holds here
     cx.c.shaded_hits++;
+    cx.last_which = shading.which;
+    cx.last_edge_margin = gl_min(gl_min(shading.uvw.x, shading.uvw.y), shading.uvw.z);
     const vec3 object_normal = triangle_interpolate_normal(*cx.scene, shading.which, shading.uvw);
     const vec3 object_color = V(1.0f, 1.0f, 1.0f);
 
@@ -623,6 +652,14 @@ vec3 sample_environment(Ctx &cx, const ray &r)
 {
     cx.c.env_lookups++;
     const Scene &sc = *cx.scene;
+    cx.env_dy = r.D.y;
+    // acos(D.y), fs:130: GLSL leaves acos undefined outside [-1, 1], and D is not a unit vector there (reflect() about a
+    // normal that is not renormalized, fs:288-295, :91): |D.y| exceeds 1 by a few 1e-6 in about one pixel of a 1080p frame.
+    // The implementations that run the reference return NaN (measured: tests/golden/glsl_reference/driver_functions.json),
+    // the lookup's colour is NaN and the pixel ends black through tonemap_and_gamma's max(0, c - .004).  So does this.
+    const bool outside_acos = !(fabsf(r.D.y) <= 1.0f);
+    const vec3 undefined_colour = V(std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN(),
+                                    std::numeric_limits<float>::quiet_NaN());
     const float dy = gl_min(gl_max(r.D.y, -1.0f), 1.0f);
     const float s = 1.0f + sr_atan2(-r.D.z, r.D.x) / tau;
     const float t = 1.0f - sr_acos(dy) / pi;
@@ -635,8 +672,12 @@ vec3 sample_environment(Ctx &cx, const ray &r)
         const float dvdy = r.dDdy.y / pi_ryy;
         if (cx.p->which == 2)   // fs:147-149: draw the dY differential
             return V(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
+        if (outside_acos)
+            return undefined_colour;
         return texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);   // fs:144-146
     }
+    if (outside_acos)
+        return undefined_colour;
     return bilinear_level(sc.env, sc.env_w, sc.env_h, s, t);   // fs:150-154: zero gradients = level 0, LINEAR
 }
 
@@ -645,6 +686,9 @@ vec3 trace(Ctx &cx, ray worldray)
 {
     vec3 accumulated = V(0, 0, 0);
     vec3 modulation = V(1, 1, 1);
+    cx.path = 0;
+    cx.first_triangle = -1;
+    cx.edge_margin = 1.0f;
     for (int i = 0; i < cx.p->bounce_count; i++) {
         ray reflected{};
         vec3 object_diffuse{}, object_specular{}, normal{};
@@ -653,10 +697,19 @@ vec3 trace(Ctx &cx, ray worldray)
             break;
         if (hit_something == 2) {
             cx.c.bad_hits++;
+            cx.path |= 1u << 30;
             return object_diffuse;
         }
+        if (i < 12)
+            cx.path |= 1u << (2 * i);
+        cx.path += 1u << 24;
+        if (i == 0)
+            cx.first_triangle = (int32_t)cx.last_which;
+        cx.edge_margin = gl_min(cx.edge_margin, cx.last_edge_margin);
         if (object_diffuse.x > 0.0f && object_diffuse.y > 0.0f && object_diffuse.z > 0.0f) {
             const vec3 diffuse_irradiance = approximate_diffuse(cx, reflected.P, normal);
+            if (cx.last_lit && i < 12)
+                cx.path |= 2u << (2 * i);
             accumulated = accumulated + modulation * object_diffuse * diffuse_irradiance;
         }
         modulation = modulation * object_specular;
@@ -781,6 +834,15 @@ void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float 
     out[1] = result.y;
     out[2] = result.z;
     out[3] = 1.0f;
+    if (g_path_map && spp == 1) {
+        g_path_map[(size_t)py * width + px] = cx.path;
+        if (g_first_triangle_map)
+            g_first_triangle_map[(size_t)py * width + px] = cx.first_triangle;
+        if (g_edge_margin_map)
+            g_edge_margin_map[(size_t)py * width + px] = cx.edge_margin;
+        if (g_env_dy_map)
+            g_env_dy_map[(size_t)py * width + px] = cx.env_dy;
+    }
     if (g_visit_map)
     {
         const uint64_t now = cx.c.node_visits + (cx.c.triangle_tests << 32), delta = now - visits_before;
@@ -876,6 +938,16 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
 
 // Diagnostics: when set, shray_oracle_render also writes node visits per pixel (width*height uint32).
 void shray_oracle_set_visit_map(uint32_t *map) { g_visit_map = map; }
+
+// Diagnostics: when set, 1 spp plain frames also write the path planes described at g_path_map (width * height each;
+// first_triangle and edge_margin may be NULL).  Pass NULLs to stop.
+void shray_oracle_set_path_map(uint32_t *path, int32_t *first_triangle, float *edge_margin, float *env_dy)
+{
+    g_path_map = path;
+    g_first_triangle_map = first_triangle;
+    g_edge_margin_map = edge_margin;
+    g_env_dy_map = env_dy;
+}
 
 // Diagnostics: records the event trace of the next renders (call with threads = 1, whole frame, in pixel order);
 // sample_offsets needs width*height*spp + 1 entries.  shray_oracle_trace_end returns the bytes the trace needed.

@@ -67,10 +67,13 @@ __device__ __forceinline__ float atan_yx(float y, float x)
     return y < 0.0f ? -angle : angle;
 }
 __device__ __forceinline__ float acos_clamped(float c) { return atan_yx(sqrtf((1.0f - c) * (1.0f + c)), c); }
+// pow(b, 5.0), fs:481: b^5 for b >= 0; NaN for a negative base, as the GL implementations' exp2(5 log2 b) gives (the
+// oracle's sr_pow5 has the measurement): such a pixel ends black through the tone map's max(0, c - .004)
 __device__ __forceinline__ float pow5(float b)
 {
     const float b2 = b * b;
-    return (b2 * b2) * b;
+    const float p = (b2 * b2) * b;
+    return b < 0.0f ? __uint_as_float(0x7fc00000u) : p;
 }
 
 // column-major mat4 times (v, w)
@@ -155,11 +158,19 @@ __device__ __forceinline__ void lookup_coords(V3 d, float &s, float &t)
 }
 
 // sample_environment, fs:127-155 with which == 0: level-0 bilinear, REPEAT wrap
+// acos(d.y) is undefined for |d.y| > 1 (d is not a unit vector: reflections about normals that are not renormalized), NaN on
+// the GL implementations that run the reference: the lookup's colour is NaN there (the oracle's sample_environment has the
+// measurement), which the tone map's max(0, c - .004) turns into a black pixel.
+__device__ __forceinline__ V3 outside_acos_is_nan(V3 colour, float dy)
+{
+    const float nan = __uint_as_float(0x7fc00000u);
+    return fabsf(dy) <= 1.0f ? colour : mk(nan, nan, nan);
+}
 __device__ __forceinline__ V3 environment(const SceneView &sc, V3 d)
 {
     float s, t;
     lookup_coords(d, s, t);
-    return environment_level(sc.env, sc.env_w, sc.env_h, s, t);
+    return outside_acos_is_nan(environment_level(sc.env, sc.env_w, sc.env_h, s, t), d.y);
 }
 
 // log2 of a finite positive float as an explicit fp32 sequence (identical in the oracle):
@@ -300,7 +311,7 @@ __device__ __forceinline__ V3 environment_with_differentials(const SceneView &sc
         return mk(fabsf(dudy) * 1.0f * 100, fabsf(dvdy) * 1.0f * 100, 0.0f);
     float s, t;
     lookup_coords(D, s, t);
-    return texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy);
+    return outside_acos_is_nan(texture_grad(sc, s, t, dudx, dvdx, dudy, dvdy), D.y);
 }
 
 // get_environment_map_coords, fs:121-125

@@ -66,7 +66,8 @@ int shray_host_get_world_info(const shray_host_world *world, shray_host_world_in
     info->leaf_count = world->stats.leaf_count;
     info->max_level = world->stats.max_level;
     info->large_leaves = world->stats.large_leaves;
-    info->build_seconds = world->load_seconds;
+    info->parse_seconds = w->parse_seconds + w->extent_seconds;   // file -> triangle_set, centre + extent
+    info->build_seconds = w->build_seconds;                       // make_bvh
     return 0;
 }
 

@@ -161,7 +161,8 @@ world_ptr load_world(const std::string &filename)
         return nullptr;
     }
     w->triangles->finish();
-    host_info("Parsing: %f seconds\n", seconds_since(then));
+    w->parse_seconds = seconds_since(then);
+    host_info("Parsing: %f seconds\n", w->parse_seconds);
 
     triangle_set &mesh = *w->triangles;
     w->triangle_count = (int)mesh.triangles.size();
@@ -177,12 +178,14 @@ world_ptr load_world(const std::string &filename)
         }
     }
     w->scene_extent = sqrtf(farthest_squared) * 2;
-    host_info("Finding scene center and extent: %f seconds\n", seconds_since(then));
+    w->extent_seconds = seconds_since(then);
+    host_info("Finding scene center and extent: %f seconds\n", w->extent_seconds);
 
     then = std::chrono::steady_clock::now();
     reset_bvh_stats();
     w->root = make_bvh(w->triangles, 0, (unsigned int)w->triangle_count);
-    host_info("BVH: %f seconds\n", seconds_since(then));
+    w->build_seconds = seconds_since(then);
+    host_info("BVH: %f seconds\n", w->build_seconds);
     if (bvh_options().verbose && !g_host_quiet)
         print_bvh_stats();
     return w;

@@ -35,6 +35,10 @@ struct world {
     float object_matrix[16], object_inverse[16];
     float object_normal_matrix[16], object_normal_inverse[16];
 
+    // what load_world spent where (the reference prints these, world.cpp:93, :109, :116): file -> triangle_set;
+    // centre + extent; make_bvh
+    double parse_seconds = 0, extent_seconds = 0, build_seconds = 0;
+
     world();
     ~world();
     world(const world &) = delete;

@@ -102,6 +102,11 @@ def cases(pkg):
     out["million_gold_constant_192"].update(max_rel=1e-2, bad_fraction=0.08, flips=210,
                                             why="three mirror bounces off a 1M-facet bumpy sphere amplify the compiler's last-bit differences: "
                                                 "median 2e-7, 94.5 % of the pixels within 1e-4, 0.5 % beyond 1e-2; the capped pixel is the same pixel")
+    # -- the same two scenes where the frame is well conditioned (round 4): glazed plaster (specular 0.05 damps what a mirror
+    #    bounce amplifies by a factor of 20) under the CONSTANT environment (no texture filter, no acos): the deep tree's
+    #    primary traversal and its shadow rays, and the bunny-class mesh's, are held to 1e-4 off the discontinuities
+    out["million_plaster_constant_192"] = _world_case(pkg, helpers.million_obj(), constant, 192, 108, 6)
+    out["bunny_plaster_constant_256"] = _world_case(pkg, helpers.bunny_trisrc(), constant, 256, 256, 6, rotate=1)
     # -- every material of the reference's table (ray.cpp:54-65) and every diffuse colour (:68-73), an object moved off the
     #    origin, a closer camera: the uniforms of ray.cpp:648-704 one by one
     for material in range(7):

@@ -236,17 +236,22 @@ def test_environment_storage_float32_and_unorm8(pkg, gpu, oracle_mod, which):
     scene.close()
 
 
-def test_kernels_match_the_reference_shaders(pkg, gpu):
+def test_kernels_match_the_reference_shaders(pkg, gpu, oracle_mod):
     """The HIP kernels against frames rendered by the REFERENCE'S OWN GLSL (tests/golden/glsl_reference/*.npz: raytracer.vs +
-    raytracer.es.fs, unmodified, on Mesa's llvmpipe; tests/test_reference_shader.py has the whole story): every case that
-    is asserted for the oracle holds for every kernel, through the C ABI, within the same bounds."""
+    raytracer.es.fs, unmodified, on Mesa's llvmpipe).  tests/test_reference_shader.py holds the ORACLE to those frames -- every
+    pixel outside 1e-4 classified, none unexplained --; here every kernel, through the C ABI, renders every one of those
+    cases bit-identical to the oracle, so that the same statement holds for the kernels' frames pixel by pixel (and the
+    count of pixels outside 1e-4 of the reference's frame is the oracle's)."""
     import glsl_cases
     N = pkg._native
     checked = 0
     for name, case in glsl_cases.cases(pkg).items():
-        if case["recorded"]:
-            continue
         want = np.load(os.path.join(glsl_cases.FIXTURES, name + ".npz"))["frame"]
+        try:
+            oracle_mod.set_env_storage(case["env_storage"])
+            stated, _ = oracle_mod.render(case["scene"][0], case["env"], case["params"], case["width"], case["height"], 1)
+        finally:
+            oracle_mod.set_env_storage(0)
         scene = pkg.Scene(case["scene"][0], None, device=0)
         scene.set_environment(case["env"], N.ENV_UNORM8 if case["env_storage"] else N.ENV_FLOAT32)
         for kernel in KERNELS:
@@ -255,13 +260,11 @@ def test_kernels_match_the_reference_shaders(pkg, gpu):
             except N.ShrayError:
                 continue            # a chain of leaves is not a binary tree: the literal kernel only
             got = scene.render(case["params"], case["width"], case["height"], 1)
-            bad = glsl_cases.out_of_tolerance(got, want)
-            rel = (np.abs(got - want)[..., :3] / np.maximum(np.abs(want[..., :3]), 1e-2)).max(axis=-1)
-            assert (rel > case["max_rel"]).sum() <= case["flips"] and bad.sum() <= case["bad_fraction"] * bad.size, \
-                (name, kernel, int(bad.sum()), float(rel.max()))
+            assert np.array_equal(got.view(np.uint32), stated.view(np.uint32)), (name, kernel)
+            assert glsl_cases.out_of_tolerance(got, want).sum() == glsl_cases.out_of_tolerance(stated, want).sum()
             checked += 1
         scene.close()
-    assert checked >= 40
+    assert checked >= 150
 
 
 def test_empty_world_renders_environment(pkg, gpu, oracle_mod, tmp_path):

@@ -296,6 +296,8 @@ def test_specified_transcendentals_are_accurate(oracle_mod):
     assert oracle_mod.atan2(0.0, -1.0) == float(np.float32(np.pi)) and oracle_mod.atan2(1.0, 0.0) == float(np.float32(np.pi / 2))
     for b in (0.0, 1.0, 0.5, 0.999, 1e-3, 0.37):
         assert oracle_mod.pow5(b) == pytest.approx(b ** 5, rel=4e-7, abs=1e-45)
+    # a negative base: undefined in GLSL, NaN on the implementations that run the reference (exp2(5 log2 x)), NaN here
+    assert np.isnan(oracle_mod.pow5(-1e-8)) and np.isnan(oracle_mod.pow5(-1.0)) and oracle_mod.pow5(-0.0) == 0.0
 
 
 # ---- the shader's `which` views (raytracer.es.fs:27, :144-154, :642-673)

@@ -56,30 +56,82 @@ def agreement(got, want, max_rel=None):
     return int(bad.sum()), bad.size, float(np.median(rel)), (float(rel.max()) if max_rel is None else int((rel > max_rel).sum()))
 
 
+def own_tolerance(case):
+    """the shader's debug views (100 x differences of lookup coordinates; the 5 x 5 supersampled view) and the 8-bit
+    background, whose texels this driver filters with 8-bit weights: held to a tolerance of their own, not classified"""
+    return case["params"].which != 0 or case["bad_fraction"] >= 1.0
+
+
 def test_oracle_matches_the_reference_shaders(all_cases, oracle_mod):
+    """Every plain-view case: a pixel of the oracle's frame further than 1e-4 from the reference shaders' must be
+    EXPLAINED (tests/pixel_classifier.py): within one pixel of a change of path -- which bounces hit, which hits were lit,
+    the iteration-cap marker -- or where the oracle's own pixel moves as far when its inputs are perturbed by what the
+    driver's acos / atan / arithmetic are measured to be off by.  No unexplained pixel is allowed, in any asserted case; and
+    the well-conditioned pixels, which are thereby all within 1e-4, are most of every frame but the 1M-facet sphere's."""
+    import pixel_classifier
     report = []
     asserted = 0
     for name, case in all_cases.items():
         want = load_fixture(name)["frame"]
-        got = oracle_frame(oracle_mod, case)
-        bad, pixels, median, worst = agreement(got, want)
-        report.append(f"{name}: {bad} of {pixels} pixels outside 1e-4; median {median:.1e} max {worst:.1e}"
+        if own_tolerance(case):             # the shader's debug views, the 8-bit background: their own tolerances, below
+            continue
+        verdict = pixel_classifier.classify(oracle_mod, case, want)
+        well = verdict["pixels"] - verdict["ill_conditioned_pixels"]
+        report.append(f"{name}: {verdict['bad']} of {verdict['pixels']} pixels outside 1e-4 -- {verdict['discontinuity']} at a change of path, "
+                      f"{verdict['sensitivity']} within the perturbation budget, {verdict['edge']} at a shared edge, {verdict['unexplained']} UNEXPLAINED "
+                      f"(worst {verdict['worst_unexplained']:.1e}); {well} well-conditioned pixels, all within 1e-4"
                       + (f"   [recorded only: {case['why']}]" if case["recorded"] else ""))
         if case["recorded"]:
             continue
         asserted += 1
-        assert agreement(got, want, case["max_rel"])[3] <= case["flips"], report[-1]
-        assert bad <= case["bad_fraction"] * pixels, report[-1]
-        assert np.all(want[..., 3] == 1.0) and np.all(got[..., 3] == 1.0)
+        assert verdict["unexplained"] == 0, report[-1]
+        assert well >= (0.2 if name.startswith("million") else 0.35) * verdict["pixels"], report[-1]
+        assert np.all(want[..., 3] == 1.0) and np.all(verdict["frame"][..., 3] == 1.0)
     print("\n".join(report))
-    assert asserted >= 39
+    assert asserted >= 37
+    # the debug views (100 x differences of lookup coordinates: fs:135-149, :642-673) and the 5 x 5 supersampled view keep
+    # a tolerance of their own
+    for name, case in all_cases.items():
+        if not own_tolerance(case) or case["recorded"]:
+            continue
+        want = load_fixture(name)["frame"]
+        got = oracle_frame(oracle_mod, case)
+        bad, pixels, _, _ = agreement(got, want)
+        assert agreement(got, want, case["max_rel"])[3] <= case["flips"] and bad <= case["bad_fraction"] * pixels, name
     # the cases no texture filter and no transcendental of the compiler's touches are exact to float rounding
     for name in ("kat_mirror_quad", "kat_plaster_quad", "kat_iteration_cap_401", "kat_iteration_cap_400", "kat_eleven_triangle_leaf"):
         assert agreement(oracle_frame(oracle_mod, all_cases[name]), load_fixture(name)["frame"])[3] < 1e-6, name
     # and the traversal / shading cases (constant environment) hold north_star's 1e-4 on all but a handful of pixels
-    for name in ("lobed_gold_constant", "lobed_plaster_constant", "lobed_plaster_constant_rotated", "quads_obj_chrome_constant"):
+    for name in ("lobed_gold_constant", "lobed_plaster_constant", "lobed_plaster_constant_rotated", "quads_obj_chrome_constant",
+                 "bunny_gold_constant_256", "bunny_plaster_constant_256"):
         bad, pixels, _, worst = agreement(oracle_frame(oracle_mod, all_cases[name]), load_fixture(name)["frame"])
-        assert bad <= 3 and worst < 2.5e-4, (name, bad, worst)
+        assert bad <= 3, (name, bad, worst)
+
+
+def test_the_classifier_does_not_explain_everything(all_cases, oracle_mod):
+    """The classifier must be able to fail: the recorded cases, where the driver does something the oracle does not state
+    (a smeared anisotropic lookup at zero derivatives, operations on NaN), leave thousands / all of their bad pixels
+    unexplained; and an oracle frame with a wrong material is not explained away either."""
+    import pixel_classifier
+    smeared = pixel_classifier.classify(oracle_mod, all_cases["lobed_gold_sky_anisotropic4"], load_fixture("lobed_gold_sky_anisotropic4")["frame"])
+    assert smeared["unexplained"] > 1000, smeared["unexplained"]
+    wrong = dict(all_cases["bunny_plaster_constant_256"])
+    wrong["params"] = wrong["params"].copy()
+    wrong["params"].diffuse_color[0] *= 1.001          # a tenth of a per cent more diffuse red
+    off = pixel_classifier.classify(oracle_mod, wrong, load_fixture("bunny_plaster_constant_256")["frame"])
+    assert off["unexplained"] > 1000, off["unexplained"]
+
+
+def test_driver_function_deviations_are_the_committed_ones():
+    """tests/golden/measure_glsl_functions.py's measurements of the driver behind the fixtures: its acos is the one
+    built-in that is far off (1.6e-4 rad; the oracle's explicit sequence: 2.8e-7) -- what the sky cases' pixels outside 1e-4
+    are (|grad env| x that deviation) --; normalize, division and the square roots are correctly rounded."""
+    import pixel_classifier
+    d = pixel_classifier.driver_functions()
+    assert 1e-4 < d["acos_abs_dev_driver"] < 2e-4 and d["acos_abs_dev_oracle"] < 4e-7
+    assert d["atan_abs_dev_driver"] < 5e-6 and d["atan_abs_dev_oracle"] < 4e-7
+    assert d["pow5_rel_dev_driver"] < 1e-5 and d["pow5_rel_dev_oracle"] < 4e-7
+    assert max(d["normalize_abs_dev_driver"], d["division_rel_dev_driver"], d["sqrt_rel_dev_driver"], d["inversesqrt_rel_dev_driver"]) < 1.2e-7
 
 
 def test_unsized_background_is_eight_bit_on_this_driver(all_cases, oracle_mod):
@@ -129,3 +181,42 @@ def test_live_reference_shader_reproduces_a_fixture(all_cases, oracle_mod):
     assert "llvmpipe" in log
     # (llvmpipe compiles the shaders for the host's vector width: allow the last bits to differ between machines)
     assert agreement(frame, load_fixture("lobed_plaster_constant_rotated")["frame"])[3] < 1e-5
+
+
+@pytest.mark.parametrize("which", ["configs[1]: gold under the HDR sky", "glazed plaster under the HDR sky", "gold, constant environment",
+                                   "configs[3]'s 1M-triangle OBJ, gold, constant environment"])
+def test_live_reference_shader_at_full_size(pkg, oracle_mod, which):
+    """BASELINE's 1920x1080 frames, where the reference's shaders can run (this container: 1.7 s a frame on llvmpipe): the
+    same classifier, no unexplained pixel; the figures are printed (pytest -s) and quoted in DESIGN.md section 2."""
+    import helpers
+    import pixel_classifier
+    if not oracle_mod.reference_shader_available():
+        pytest.skip("the reference tree / Mesa software driver / harness is not on this box")
+    W, H = 1920, 1080
+    million = which.startswith("configs[3]")
+    world = pkg.World(helpers.million_obj() if million else helpers.bunny_trisrc())
+    env = pkg.scenes.environment_hdr_sky(2048) if "sky" in which else pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    params = world.frame_params(W, H, material=6 if "plaster" in which else 0)
+    case = dict(scene=(world.flatten(), world), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=W, height=H,
+                env_storage=0)
+    want, _ = oracle_mod.render_reference_shader(case["scene"][0], case["env"], params, W, H, 0, 1.0)
+    verdict = pixel_classifier.classify(oracle_mod, case, want)
+    got = verdict["frame"]
+    rel = (np.abs(got - want)[..., :3] / np.maximum(np.abs(want[..., :3]), 1e-2)).max(axis=-1)
+    print(f"\n{which}, {W}x{H}: {verdict['bad']} of {verdict['pixels']} pixels outside 1e-4 ({100.0 * verdict['bad'] / verdict['pixels']:.3f} %), "
+          f"{int((rel > 1e-3).sum())} beyond 1e-3, {int((rel > 1e-2).sum())} beyond 1e-2; {verdict['discontinuity']} at a change of path, "
+          f"{verdict['sensitivity']} within the perturbation budget, {verdict['edge']} at a shared edge (of {verdict['edge_candidates']} such pixels), "
+          f"{verdict['unexplained']} unexplained; "
+          f"{verdict['pixels'] - verdict['ill_conditioned_pixels']} well-conditioned pixels")
+    assert verdict["unexplained"] == 0
+    if million:
+        # the iteration cap's red marker (fs:436-438): the reference's pixels and the oracle's are not all the same ones at
+        # this size -- a capped ray sits at the end of 400 visits, any of whose box tests a last bit can turn -- but every
+        # one of them, on either side, is an ill-conditioned pixel by the classifier, and their numbers are close
+        from test_oracle_kat import filmic64
+        red = np.asarray(filmic64([1.0, 0.0, 0.0]), dtype=np.float32)
+        marked = lambda frame: np.all(np.abs(frame[..., :3] - red) < 1e-5, axis=-1)   # noqa: E731
+        theirs, ours = marked(want), marked(got)
+        print(f"marker pixels: the reference's {int(theirs.sum())}, the oracle's {int(ours.sum())}, in common {int((theirs & ours).sum())}")
+        assert theirs.sum() >= 1 and ours.sum() >= 1 and abs(int(theirs.sum()) - int(ours.sum())) <= 0.25 * theirs.sum()
+        assert not (verdict["unexplained_mask"] & (theirs ^ ours)).any()

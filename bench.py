@@ -176,13 +176,24 @@ def main():
     if distributed:
         dist.barrier()
     path = helpers.bunny_trisrc()
+    t_load = time.perf_counter()
     world = pkg.World(path)
+    t_flatten = time.perf_counter()
     desc = world.flatten()
+    t_flattened = time.perf_counter()
     env = pkg.scenes.environment_hdr_sky(2048)
     orbit = orbit_params(pkg, world, WIDTH, HEIGHT, args.material)
     if args.same_view:
         orbit = [orbit[0]] * ORBIT
+    t_create = time.perf_counter()
     scene = pkg.Scene(desc, env, device=local_rank)
+    torch.cuda.synchronize()
+    # file -> resident scene (the reference prints the same pieces: world.cpp:93-116)
+    turnaround = {"parse_s": round(world.info.parse_seconds, 4), "bvh_build_s": round(world.info.build_seconds, 4),
+                  "flatten_s": round(t_flattened - t_flatten, 4), "validate_repack_upload_s": round(time.perf_counter() - t_create, 4),
+                  "load_world_s": round(t_flatten - t_load, 4), "triangles": int(world.triangle_count),
+                  "host_threads": int(os.environ.get("SHRAY_LOAD_THREADS", 0)) or min(os.cpu_count() or 1, 32),
+                  "what": "bunny-class trisrc (21 MB of text) -> triangle_set -> BVH -> get_shader_data arrays -> shray_scene_create + environment"}
     scene.set_kernel(args.kernel)
 
     from shader_ray_amd import multigpu
@@ -404,7 +415,7 @@ def main():
                       "clock has ramped before the first trial",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frames_verified": frames_compared - frames_differing, "frames_mismatched": frames_differing,
-            "rccl_ranks": rccl_ranks, "transport_fallback": transport_fallback,
+            "rccl_ranks": rccl_ranks, "transport_fallback": transport_fallback, "scene_turnaround": turnaround,
             "config": {"workload": "bunny-class trisrc (69,168 triangles, synthetic stand-in for bunny.trisrc) + seeded "
                                    f"2048x1024 HDR sky, {WIDTH}x{HEIGHT}, {SPP} spp, "
                                    + ("gold" if args.material == 0 else f"material {args.material}") + ", 3 bounces"

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Scene turnaround: seconds from a model file to a resident scene, step by step,
+for the two BASELINE scenes, with the loaders on one thread (the reference's way) and on the box's threads.
+    python profiles/scene_turnaround.py [out.json]        (run on the GPU box)"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import json, os, sys, time
+sys.path[:0] = [%r, %r]
+import torch
+from __graft_entry__ import load_package
+import helpers
+pkg = load_package()
+torch.zeros(1, device="cuda")
+rows = []
+for name, path in (("bunny-class trisrc", helpers.bunny_trisrc()), ("1M-triangle obj", helpers.million_obj())):
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter(); world = pkg.World(path)
+        t1 = time.perf_counter(); desc = world.flatten()
+        t2 = time.perf_counter(); scene = pkg.Scene(desc, pkg.scenes.environment_constant(), device=0); torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        row = {"scene": name, "file_MB": round(os.path.getsize(path) / 1e6, 1), "triangles": int(world.triangle_count),
+               "parse_s": round(world.info.parse_seconds, 3), "bvh_build_s": round(world.info.build_seconds, 3),
+               "flatten_s": round(t2 - t1, 3), "validate_repack_upload_s": round(t3 - t2, 3), "total_s": round(t3 - t0, 3)}
+        scene.close()
+        if best is None or row["total_s"] < best["total_s"]:
+            best = row
+    rows.append(best)
+print(json.dumps(rows))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+
+out = {}
+for threads in ("1", ""):
+    env = dict(os.environ)
+    if threads:
+        env["SHRAY_LOAD_THREADS"] = threads
+        env["SHRAY_BVH_THREADS"] = "0"
+    else:
+        env.pop("SHRAY_LOAD_THREADS", None)
+        env.pop("SHRAY_BVH_THREADS", None)
+    text = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, check=True).stdout
+    out["one thread (the reference's way)" if threads else f"the box's threads ({min(os.cpu_count() or 1, 32)} used of {os.cpu_count()})"] = json.loads(text.strip().splitlines()[-1])
+    print(threads or "all", text.strip().splitlines()[-1], flush=True)
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "scene_turnaround.json")
+json.dump(out, open(path, "w"), indent=1)

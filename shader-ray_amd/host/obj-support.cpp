@@ -12,7 +12,11 @@
 // are undefined behaviour upstream; here they fail the load.
 //
 // Unlike the reference this parser keeps faces in flat arrays and scans the
-// file in place, so the 1M-triangle benchmark mesh loads in well under a second.
+// file in place; since round 4 in parallel: the text is cut at line ends into one piece per thread, each piece is scanned
+// into arrays of its own and the arrays are appended in file order (a face's indices are absolute, so nothing has to
+// be renumbered); the synthesized normals are summed per vertex in face order by the thread that owns the vertex (the
+// float sums are those of the serial loop), and the triangles go to triangle_set::add_bulk.  Same arrays, same
+// triangle_set, bit for bit (tests/test_loaders.py compares with SHRAY_LOAD_THREADS=1).
 #include "obj-support.h"
 
 #include "host-log.h"
@@ -20,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 
 namespace {
 
@@ -136,23 +141,42 @@ void Obj::parse_face(const char *begin, const char *end)
 void Obj::synthesize_normals()
 {
     normals.assign(positions.size(), vec3(0.0f));
-    for (size_t f = 0; f < face_first.size(); f++) {
-        corner *fc = &corners[face_first[f]];
-        const unsigned int n = face_size[f];
-        for (unsigned int k = 1; k + 1 < n; k++) {
-            corner &c0 = fc[0], &c1 = fc[k], &c2 = fc[k + 1];
-            const vec3 face_normal = cross(positions[c1.v] - positions[c0.v], positions[c2.v] - positions[c0.v]);
-            face_attribs[f] |= HAS_NORMAL;
-            c0.vn = c0.v;
-            c1.vn = c1.v;
-            c2.vn = c2.v;
-            normals[c0.vn] = normals[c0.vn] + face_normal;
-            normals[c1.vn] = normals[c1.vn] + face_normal;
-            normals[c2.vn] = normals[c2.vn] + face_normal;
+    const int threads = host_load_threads();
+    // every corner's normal index is its position index; the faces have normals now
+    host_in_parallel(threads, [&](int j) {
+        const size_t lo = face_first.size() * (size_t)j / threads, hi = face_first.size() * (size_t)(j + 1) / threads;
+        for (size_t f = lo; f < hi; f++) {
+            if (face_size[f] >= 3)
+                face_attribs[f] |= HAS_NORMAL;
+            corner *fc = &corners[face_first[f]];
+            for (unsigned int k = 0; k < face_size[f]; k++)
+                if (face_size[f] >= 3)
+                    fc[k].vn = fc[k].v;
         }
-    }
-    for (vec3 &n : normals)
-        n = normalize(n);
+    });
+    // a vertex's normal is the sum of the face normals of the triangles that use it, added in face order, fan order and
+    // corner order (obj-support.cpp:104-146): thread j adds for the vertices [lo, hi) it owns and walks every face
+    host_in_parallel(threads, [&](int j) {
+        const size_t lo = positions.size() * (size_t)j / threads, hi = positions.size() * (size_t)(j + 1) / threads;
+        for (size_t f = 0; f < face_first.size(); f++) {
+            const corner *fc = &corners[face_first[f]];
+            const unsigned int n = face_size[f];
+            for (unsigned int k = 1; k + 1 < n; k++) {
+                const unsigned int v[3] = {fc[0].v, fc[k].v, fc[k + 1].v};
+                if (!((v[0] >= lo && v[0] < hi) || (v[1] >= lo && v[1] < hi) || (v[2] >= lo && v[2] < hi)))
+                    continue;
+                const vec3 face_normal = cross(positions[v[1]] - positions[v[0]], positions[v[2]] - positions[v[0]]);
+                for (int c = 0; c < 3; c++)
+                    if (v[c] >= lo && v[c] < hi)
+                        normals[v[c]] = normals[v[c]] + face_normal;
+            }
+        }
+    });
+    host_in_parallel(threads, [&](int j) {
+        const size_t lo = normals.size() * (size_t)j / threads, hi = normals.size() * (size_t)(j + 1) / threads;
+        for (size_t k = lo; k < hi; k++)
+            normals[k] = normalize(normals[k]);
+    });
 }
 
 bool Obj::indices_in_range(std::string *why) const
@@ -173,10 +197,9 @@ bool Obj::indices_in_range(std::string *why) const
     return true;
 }
 
-bool Obj::load_object_from_text(const char *text, size_t length)
+void Obj::scan_lines(const char *text, const char *text_end)
 {
     const char *p = text;
-    const char *const text_end = text + length;
     while (p < text_end) {
         const char *eol = (const char *)memchr(p, '\n', (size_t)(text_end - p));
         if (!eol)
@@ -211,9 +234,50 @@ bool Obj::load_object_from_text(const char *text, size_t length)
         } else if (type_len == 1 && line[0] == 'f') {
             parse_face(payload, eol);
         } else if (type_len == 1 && line[0] == 'o') {
-            host_info("obj: object '%.*s'\n", (int)(eol - payload), payload);
+            object_names.emplace_back(payload, (size_t)(eol - payload));
         }
     }
+}
+
+// the arrays of the next piece of the file, behind this one's
+void Obj::append(Obj &&chunk)
+{
+    const size_t corner_offset = corners.size();
+    positions.insert(positions.end(), chunk.positions.begin(), chunk.positions.end());
+    normals.insert(normals.end(), chunk.normals.begin(), chunk.normals.end());
+    texcoords.insert(texcoords.end(), chunk.texcoords.begin(), chunk.texcoords.end());
+    corners.insert(corners.end(), chunk.corners.begin(), chunk.corners.end());
+    for (size_t first : chunk.face_first)
+        face_first.push_back(first + corner_offset);
+    face_size.insert(face_size.end(), chunk.face_size.begin(), chunk.face_size.end());
+    face_attribs.insert(face_attribs.end(), chunk.face_attribs.begin(), chunk.face_attribs.end());
+    for (std::string &name : chunk.object_names)
+        object_names.push_back(std::move(name));
+}
+
+bool Obj::load_object_from_text(const char *text, size_t length)
+{
+    // one piece per thread, cut behind a line end; pieces of less than 256 KB are not worth a thread
+    const int threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_load_threads(), length >> 18));
+    std::vector<const char *> cut(1, text);
+    for (int j = 1; j < threads; j++) {
+        const char *at = text + length * (size_t)j / (size_t)threads;
+        if (at < cut.back())
+            at = cut.back();
+        const char *eol = (const char *)memchr(at, '\n', (size_t)(text + length - at));
+        cut.push_back(eol ? eol + 1 : text + length);
+    }
+    cut.push_back(text + length);
+    if (threads == 1) {
+        scan_lines(text, text + length);
+    } else {
+        std::vector<Obj> piece((size_t)threads);
+        host_in_parallel(threads, [&](int j) { piece[(size_t)j].scan_lines(cut[(size_t)j], cut[(size_t)j + 1]); });
+        for (Obj &chunk : piece)
+            append(std::move(chunk));
+    }
+    for (const std::string &name : object_names)
+        host_info("obj: object '%s'\n", name.c_str());
 
     host_info("obj: %zu faces, %zu positions, %zu normals, %zu texcoords\n", face_first.size(), positions.size(),
             normals.size(), texcoords.size());
@@ -246,25 +310,40 @@ bool Obj::load_object_from_file(const std::string &filename)
 
 bool Obj::fill_triangle_set(triangle_set_ptr triangles)
 {
-    for (size_t f = 0; f < face_first.size(); f++) {
-        const corner *fc = &corners[face_first[f]];
-        const bool with_normals = (face_attribs[f] & HAS_NORMAL) != 0;
-        for (unsigned int k = 1; k + 1 < face_size[f]; k++) {
-            const corner *pick[3] = {&fc[0], &fc[k], &fc[k + 1]};
-            vertex vtx[3];
-            for (int j = 0; j < 3; j++) {
-                vtx[j].v = positions[pick[j]->v];
-                if (with_normals) {
-                    if (pick[j]->vn >= normals.size()) {
-                        fprintf(stderr, "obj: a face names a normal that does not exist\n");
-                        return false;
+    // triangle_first[f] = the number of the first fan triangle of face f
+    std::vector<size_t> triangle_first(face_first.size() + 1, 0);
+    for (size_t f = 0; f < face_first.size(); f++)
+        triangle_first[f + 1] = triangle_first[f] + (face_size[f] >= 3 ? face_size[f] - 2 : 0);
+    std::vector<vertex> tri_corners(3 * triangle_first.back());
+    const int threads = host_load_threads();
+    std::vector<char> missing_normal((size_t)threads, 0);
+    host_in_parallel(threads, [&](int j) {
+        const size_t lo = face_first.size() * (size_t)j / threads, hi = face_first.size() * (size_t)(j + 1) / threads;
+        for (size_t f = lo; f < hi; f++) {
+            const corner *fc = &corners[face_first[f]];
+            const bool with_normals = (face_attribs[f] & HAS_NORMAL) != 0;
+            vertex *out = tri_corners.data() + 3 * triangle_first[f];
+            for (unsigned int k = 1; k + 1 < face_size[f]; k++) {
+                const corner *pick[3] = {&fc[0], &fc[k], &fc[k + 1]};
+                for (int c = 0; c < 3; c++, out++) {
+                    out->v = positions[pick[c]->v];
+                    if (with_normals) {
+                        if (pick[c]->vn >= normals.size()) {
+                            missing_normal[(size_t)j] = 1;
+                            continue;
+                        }
+                        out->n = normals[pick[c]->vn];
                     }
-                    vtx[j].n = normals[pick[j]->vn];
+                    out->c = vec3(1.0f, 1.0f, 1.0f);
                 }
-                vtx[j].c = vec3(1.0f, 1.0f, 1.0f);
             }
-            triangles->add(vtx[0], vtx[1], vtx[2]);
         }
-    }
+    });
+    for (char missing : missing_normal)
+        if (missing) {
+            fprintf(stderr, "obj: a face names a normal that does not exist\n");
+            return false;
+        }
+    triangles->add_bulk(tri_corners.data(), triangle_first.back(), threads);
     return true;
 }

@@ -44,6 +44,10 @@ private:
     std::vector<unsigned int> face_size;
     std::vector<unsigned int> face_attribs;
 
+    std::vector<std::string> object_names;      // the `o` lines, in file order
+
+    void scan_lines(const char *begin, const char *end);
+    void append(Obj &&chunk);
     void parse_attribute(const char *begin, const char *end, vec3 &out);
     void parse_face(const char *begin, const char *end);
     void synthesize_normals();

@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -28,6 +30,16 @@
 #include "host-log.h"
 #include "obj-support.h"
 #include "trisrc-support.h"
+
+int host_load_threads()
+{
+    static const int threads = [] {
+        if (const char *s = getenv("SHRAY_LOAD_THREADS"))
+            return std::max(1, atoi(s));
+        return (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    }();
+    return threads;
+}
 
 namespace {
 

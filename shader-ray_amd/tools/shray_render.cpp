@@ -32,6 +32,7 @@
 #include "shader_ray_dist.h"
 #include "shader_ray_hip.h"
 #include "world.h"
+#include "host-log.h"
 
 namespace {
 
@@ -171,7 +172,9 @@ int main(int argc, char **argv)
     const int env_w = background.width, env_h = background.height;
 
     scene_shader_data data;
+    const auto flatten_began = std::chrono::steady_clock::now();
     get_shader_data(world, data, 2048);
+    const double flatten_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - flatten_began).count();
     shray_scene_desc desc;
     memset(&desc, 0, sizeof(desc));
     desc.struct_size = sizeof(desc);
@@ -286,10 +289,17 @@ int main(int argc, char **argv)
         }
         frames = 0;   // no per-frame histogram: the loop's rate is printed above
     } else {
+        const auto create_began = std::chrono::steady_clock::now();
         if (shray_scene_create(&desc, &scene) != SHRAY_OK || shray_scene_set_environment(scene, env.data(), env_w, env_h) != SHRAY_OK) {
             fprintf(stderr, "GPU setup failed: %s\n", shray_last_error());
             return EXIT_FAILURE;
         }
+        // scene turnaround, file to resident scene (what the reference prints piecewise: world.cpp:93-116, ray.cpp:470-510)
+        fprintf(stderr, "scene turnaround: parse %.3f s, centre + extent %.3f s, BVH %.3f s, flatten %.3f s, validate + repack + upload "
+                "(with the environment) %.3f s; %d triangles, %d threads\n", world->parse_seconds, world->extent_seconds,
+                world->build_seconds, flatten_seconds,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - create_began).count(), world->triangle_count,
+                host_load_threads());
         for (int frame = 0; frame < std::max(frames, 1); frame++) {
             advance_view(frame);
             const auto then = std::chrono::steady_clock::now();

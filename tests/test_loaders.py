@@ -174,3 +174,55 @@ def test_threaded_bvh_build_equals_the_serial_build(pkg):
     env = dict(os.environ, SHRAY_BVH_THREADS="0")
     serial = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()[-1]
     assert threaded == serial
+
+
+def _digest_in_a_process(paths, threads):
+    """sha256 of World(path).arrays() for each path, in a fresh process with SHRAY_LOAD_THREADS = threads (the loaders read
+    it once); '!' where the load fails"""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib, numpy as np; sys.path[:0] = [%r, %r]\n"
+            "from __graft_entry__ import load_package\n"
+            "pkg = load_package()\n"
+            "for path in %r:\n"
+            "    try:\n"
+            "        a = pkg.World(path).arrays()\n"
+            "    except Exception:\n"
+            "        print('!'); continue\n"
+            "    h = hashlib.sha256()\n"
+            "    for k in sorted(a):\n"
+            "        v = a[k]; h.update(k.encode()); h.update(v.tobytes() if isinstance(v, np.ndarray) else str(v).encode())\n"
+            "    print(h.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"), list(paths))
+    env = dict(os.environ, SHRAY_LOAD_THREADS=str(threads))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    return out[-len(paths):]
+
+
+def test_threaded_loaders_equal_the_serial_loaders(pkg, tmp_path):
+    """Round 4: files are parsed in pieces on several threads, vertices are de-duplicated in shards (triangle_set::add_bulk)
+    and synthesized normals are summed per vertex by the thread that owns it -- the flattened arrays must be those of the
+    one-thread load (SHRAY_LOAD_THREADS=1, the reference's order of everything): same vertex numbering, same triangle
+    order, same float sums.  The BASELINE scenes, plus trisrc texts that defeat the piece-wise parse and must fall back:
+    a tag that begins with a quote after a line end (a cut lands on it), a truncated last record, foreign text at the end."""
+    rng = np.random.default_rng(7)
+
+    def records(n, tag="t"):
+        rows = []
+        for _ in range(n):
+            v = rng.uniform(-1, 1, (3, 3)).round(3)
+            rows.append(f'"*" {tag} 0.5 0.5 0.5 1 20\n' + "".join(
+                f"{p[0]} {p[1]} {p[2]} 0 0 1 0.8 0.8 0.8 1 0 0\n" for p in v))
+        return "".join(rows)
+
+    body = records(4000)                      # ~700 KB: several pieces
+    tricky = write(tmp_path / "quoted_tag.trisrc", records(2000) + records(2000, tag='\n"q'))
+    truncated = write(tmp_path / "truncated.trisrc", body + '"*" t 0.5 0.5 0.5 1 20\n0 0 0 0 0 1 1 1 1 1 0 0\n')
+    foreign = write(tmp_path / "foreign.trisrc", body + "end of file\n")
+    plain = write(tmp_path / "plain.trisrc", body)
+    paths = [helpers.bunny_trisrc(), helpers.million_obj(), os.path.join(ROOT, "tests", "golden", "quads_nonormals.obj"),
+             plain, tricky, truncated, foreign]
+    serial = _digest_in_a_process(paths, 1)
+    for threads in (3, 8):
+        assert _digest_in_a_process(paths, threads) == serial, threads
+    assert serial[5] == "!" and "!" not in serial[:5] + serial[6:]      # the truncated record fails the load either way
+    assert len(set(serial[3:5])) == 2                                    # (the tricky text is another scene than the plain one)

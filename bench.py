@@ -455,8 +455,9 @@ def main():
             costs_note = f"{ISA_COSTS} unreadable: {exc}"
         roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Gwaveinst/s", "frac": None,
                 "traffic": None,
-                "why": "the scene + environment working set (32 MB) is cache-resident: the kernel is bound by VALU issue, "
-                       "not by HBM (DESIGN.md section 4); HBM use is reported as hbm_frac"}
+                "why": "the scene + environment working set (32 MB) is cache-resident: the kernel is co-limited by VALU issue (four "
+                       "SIMDs per CU) and by the CU's one vector memory pipeline, not by HBM (DESIGN.md sections 4, 5); both are "
+                       "reported (valu_issue, vector_memory), the headline pair is the busier one; HBM use is hbm_frac"}
         if costs:
             # wave-instructions a frame would take if every lane of every instruction did arithmetic the shader asks for
             ops = algorithmic_ops(counters_timed, costs) / 64.0
@@ -506,6 +507,47 @@ def main():
                     hbm_gbs = pmc["hbm_bytes_per_launch"] / fpl * frames_per_s / 1e9
                     roof.update({"traffic": pmc["hbm_bytes_per_launch"], "traffic_frames": fpl, "hbm_gbs": round(hbm_gbs, 2),
                                  "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 5)})
+            # The vector memory pipeline: one per CU (texture addresser + vector L1 + texture data), shared by the CU's four
+            # SIMDs.  Its peak is measured HERE, on this GPU, by shray_probe_vector_cache: wave-instructions of 16 bytes per
+            # lane per second when nothing else is done and every lane reads the same record (the pipeline's floor of ~14
+            # cycles per instruction: profiles/r04/vector_cache_probe.json; lanes that read different cache lines cost more);
+            # achieved = the kernel's vector-memory instructions (SQ_INSTS_VMEM_RD of the profiled run) x frames per second
+            import ctypes as C
+            probe_waves, probe_visits = 256 * 4 * 7 * 8, 512
+            sec, nbytes = C.c_double(), C.c_uint64()
+            pkg._native.check(pkg._native.load_hip().shray_probe_vector_cache(32768, 1, probe_visits, probe_waves, 0xffffffffffffffff, 32,
+                                                                              C.byref(sec), C.byref(nbytes)))
+            vmem_peak = probe_waves * probe_visits * 2 / sec.value / 1e9          # G wave-instructions / s
+            vmem = {"peak": round(vmem_peak, 2), "unit": "Gwaveinst/s (16 bytes per lane)",
+                    "peak_source": "shray_probe_vector_cache in this run: every lane of a wave-instruction at one 32-byte record of a "
+                                   f"1 MB table, {probe_waves} one-wave workgroups x {probe_visits} visits x 2 loads in {sec.value * 1e3:.3f} ms",
+                    "achieved": None, "frac": None}
+            if pmc and pmc.get("vmem_insts_per_launch"):
+                fpl = pmc["workload"].get("frames_per_launch", 1)
+                gv = pmc["vmem_insts_per_launch"] / fpl * frames_per_s / 1e9
+                vmem.update({"achieved": round(gv, 2), "frac": round(gv / vmem_peak, 5), "vmem_insts_per_frame": pmc["vmem_insts_per_launch"] / fpl,
+                             "scalar_mem_insts_per_frame": (pmc.get("smem_insts_per_launch") or 0) / fpl,
+                             "ta_busy_frac": round(pmc["ta_busy_frac"], 4) if pmc.get("ta_busy_frac") else None,
+                             "td_busy_frac": round(pmc["td_busy_frac"], 4) if pmc.get("td_busy_frac") else None,
+                             "note": "frac prices every instruction at the floor; ta_busy_frac / td_busy_frac (TA_BUSY_avr, TD_BUSY_avr over "
+                                     "GRBM_GUI_ACTIVE / 8 of the profiled run) are how busy the pipeline was with what the lanes really read"})
+                roof["wait_frac"] = round(pmc["wait_frac"], 4) if pmc.get("wait_frac") else None
+            roof["vector_memory"] = vmem
+            roof["valu_issue"] = {"achieved": roof.get("achieved"), "peak": VALU_PEAK_GINST, "frac": roof.get("frac"), "unit": "Gwaveinst/s",
+                                  "busy_frac_profiled": round(pmc["valu_busy_frac_profiled"], 4) if pmc and pmc.get("valu_busy_frac_profiled") else None}
+            # The headline pair names the busier pipe.  Compared in ONE run, the profiled one (rocprofv3 runs a launch at a time
+            # while it counts: there a four-frame launch has the GPU to itself and every pipe is less busy than in the timed
+            # loop, whose launches overlap): VALU = 2 cycles x SQ_INSTS_VALU / (1024 SIMDs x the kernel's cycles), the vector
+            # memory pipeline = the busier of its two stages (texture addresser, texture data)
+            if pmc and pmc.get("valu_busy_frac_profiled") and (pmc.get("ta_busy_frac") or pmc.get("td_busy_frac")):
+                stage, busy = max((("texture addresser", pmc.get("ta_busy_frac") or 0.0), ("texture data", pmc.get("td_busy_frac") or 0.0)),
+                                  key=lambda kv: kv[1])
+                if busy > pmc["valu_busy_frac_profiled"]:
+                    roof.update({"bound": "vector_memory_pipeline", "frac": round(busy, 5), "peak": round(vmem_peak, 2),
+                                 "achieved": round(busy * vmem_peak, 2), "unit": "Gwaveinst/s (16 bytes per lane)",
+                                 "frac_is": f"the {stage} stage's busy fraction in the profiled run (VALU in the same run: "
+                                            f"{pmc['valu_busy_frac_profiled']:.3f}); achieved = frac x the peak measured in this run; "
+                                            "the timed loop's VALU fraction is valu_issue.frac"})
             roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                          "concurrent_launches": lanes, "frames_per_launch": batch,
                          "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed (every {EVENT_STRIDE}th)"})

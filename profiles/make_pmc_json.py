@@ -43,6 +43,18 @@ out = {
     "lane_util": (vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_INSTS_VALU"] * 64.0)) if "SQ_THREAD_CYCLES_VALU" in vals else None,
     "hbm_bytes_per_launch": int((2 * fetch + write) * 1024) if fetch is not None and write is not None else None,
     "hbm_note": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane loads) + WRITE_SIZE, KiB -> bytes, per launch",
+    # the vector memory pipeline (one texture-addresser / texture-data pair per CU, shared by the CU's four SIMDs):
+    # wave-instructions it was handed, and how busy it was while the kernel ran (TA_BUSY_avr = busy cycles averaged over
+    # the 256 instances; GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    "vmem_insts_per_launch": vals.get("SQ_INSTS_VMEM_RD"),
+    "smem_insts_per_launch": vals.get("SQ_INSTS_SMEM"),
+    # (busy cycles summed over the instances / 256 active CUs, over the kernel's own cycles GRBM_GUI_ACTIVE / 8 XCDs; rocprofv3
+    # runs one dispatch at a time while it counts, so these are fractions of a launch that has the GPU to itself)
+    "ta_busy_frac": (vals["TA_TA_BUSY_sum"] / 256.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "TA_TA_BUSY_sum" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
+    "td_busy_frac": (vals["TD_TD_BUSY_sum"] / 256.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "TD_TD_BUSY_sum" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
+    "valu_busy_frac_profiled": (vals["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "SQ_INSTS_VALU" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
+    "kernel_cycles_profiled": (vals["GRBM_GUI_ACTIVE"] / 8.0) if vals.get("GRBM_GUI_ACTIVE") else None,
+    "wait_frac": (vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in vals and vals.get("SQ_WAVE_CYCLES") else None,
     "source": summary_path,
 }
 json.dump(out, open(out_path, "w"), indent=1)

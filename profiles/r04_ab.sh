@@ -6,7 +6,7 @@ CONFIGS=""
 if [ "$1" = "-c" ]; then CONFIGS=$2; shift 2; fi
 LIBS=("")
 if [ $# -gt 0 ]; then for v in "$@"; do LIBS+=("shader-ray_amd/_variants/libshray_hip_$v.so"); done
-else for f in shader-ray_amd/_variants/*.so; do LIBS+=("$f"); done; fi
+else for f in shader-ray_amd/_variants/*.so; do [ -e "$f" ] && LIBS+=("$f"); done; fi
 for lib in "${LIBS[@]}"; do
   name=${lib:-shipped}; name=${name##*/}
   for steps in 200 20; do

@@ -152,6 +152,7 @@ struct PoolTraversal {
             // ---- one epoch of the wave-cooperative traversal (wave_traversal.h).  A leaf a lane parks in is
             //      finished before the epoch ends, so every live ray is in LT_WALK when the waves meet again.
             uint32_t *column = stack + col;
+            t.divide_mask = wave_ballot(t.divide);     // rays have moved between lanes
             int turns = 0;
             while (turns < kPoolEpochTurns && wave_ballot(state != LT_ENDED)) {
                 const int alive = __popcll(wave_ballot(state != LT_ENDED));

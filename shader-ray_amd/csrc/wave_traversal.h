@@ -67,6 +67,8 @@ struct LaneTraversal {
     V3 P, D, Y;               // object-space ray and its reciprocal direction RN(1/D) (exact_div.h); the residual of the
                               // reciprocal is recomputed where the exact quotients are needed (slab_range: a rare branch)
     bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
+    unsigned long long divide_mask;   // the wave's lanes with `divide` set (uniform; kept beside the per-lane flag because a
+                              // ballot of a flag that lives in a lane mask is materialised in a vector register first)
     uint32_t positive_dir;
     Hit hit;
     uint32_t node;
@@ -110,6 +112,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
             t.Y = mk(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     }
 #endif
+    t.divide_mask = wave_ballot(t.divide);
     t.fx = D.x >= 0.0f;
     t.fy = D.y >= 0.0f;
     t.fz = D.z >= 0.0f;
@@ -197,11 +200,16 @@ __device__ __forceinline__ void slab_range(const LaneTraversal &t, const float4 
     const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
     const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
     // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
-    const V3 YL = mk(reciprocal_residual(t.D.x, t.Y.x), reciprocal_residual(t.D.y, t.Y.y), reciprocal_residual(t.D.z, t.Y.z));
-    r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, t.Y.x, YL.x)), div_by_constant4(ey, t.D.y, t.Y.y, YL.y)),
-               div_by_constant4(ez, t.D.z, t.Y.z, YL.z));
-    r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, t.Y.x, YL.x)), div_by_constant4(xy, t.D.y, t.Y.y, YL.y)),
-               div_by_constant4(xz, t.D.z, t.Y.z, YL.z));
+    // (the residuals of the reciprocals are wanted HERE only, in a branch the wave rarely takes; computed from values the
+    // optimizer can see are loop-invariant they are hoisted in front of the node loop and spilled there -- three scratch
+    // stores per traversal on the pipe that bounds the kernel --, so the reciprocals pass through an opaque copy first)
+    V3 Y = t.Y;
+    asm volatile("" : "+v"(Y.x), "+v"(Y.y), "+v"(Y.z));
+    const V3 YL = mk(reciprocal_residual(t.D.x, Y.x), reciprocal_residual(t.D.y, Y.y), reciprocal_residual(t.D.z, Y.z));
+    r0 = fmaxf(fmaxf(fmaxf(0.0f, div_by_constant4(ex, t.D.x, Y.x, YL.x)), div_by_constant4(ey, t.D.y, Y.y, YL.y)),
+               div_by_constant4(ez, t.D.z, Y.z, YL.z));
+    r1 = fminf(fminf(fminf(kRangeMax, div_by_constant4(xx, t.D.x, Y.x, YL.x)), div_by_constant4(xy, t.D.y, Y.y, YL.y)),
+               div_by_constant4(xz, t.D.z, Y.z, YL.z));
     if (t.divide) {   // operands outside the proven ranges of exact_div.h: true division, GLSL min/max
         r0 = sel_max(sel_max(sel_max(0.0f, ex / t.D.x), ey / t.D.y), ez / t.D.z);
         r1 = sel_min(sel_min(sel_min(kRangeMax, xx / t.D.x), xy / t.D.y), xz / t.D.z);
@@ -254,11 +262,16 @@ __device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const flo
     asm("v_min_f32 %0, %1, %2" : "=v"(below) : "v"(r1), "v"(t.hit.t));
     const float lo0 = r0 * kBandDown;
     bool enter = r0 * kBandUp < below;
-    const bool unsure = !(enter || lo0 >= below) || t.divide;
+    const bool miss = lo0 >= below;
     r0 = lo0;
 #ifndef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes
-    if (__builtin_expect(wave_ballot(unsure) != 0ull, 0)) {
+    // (the wave-level test from the two comparisons' own lane masks: as one ballot of the combined condition the compiler
+    // materialises it in a vector register and compares again -- three more vector instructions per visit)
+    const unsigned long long active = wave_ballot(true);
+    const unsigned long long undecided = (active & ~(wave_ballot(enter) | wave_ballot(miss))) | (active & t.divide_mask);
+    if (__builtin_expect(undecided != 0ull, 0)) {
         asm volatile("; a visit the bounds do not decide: the exact quotients" ::: "memory");   // keeps this a branch
+        const bool unsure = !(enter || miss) || t.divide;
         if (unsure) {
             slab_range(t, lo, hi, r0, r1);
             enter = !(r0 >= r1) && (r0 < t.hit.t);
@@ -513,8 +526,15 @@ __device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &
     }
     // a hit distance that is NaN (an unordered candidate was accepted, see leaf_stage_dealt) fails `r0 < hit.t` at every
     // later visit; the visit's fast test does not look for it: such a lane takes the exact branch from here on
-    if (state == LT_LEAF)
-        t.divide = t.divide || t.hit.t != t.hit.t;
+    {
+        const unsigned long long no_distance = wave_ballot(state == LT_LEAF && t.hit.t != t.hit.t);
+        if (__builtin_expect(no_distance != 0ull, 0)) {
+            asm volatile("; a hit distance that is NaN" ::: "memory");   // keeps this a branch
+            if (state == LT_LEAF && t.hit.t != t.hit.t)
+                t.divide = true;
+            t.divide_mask |= no_distance;
+        }
+    }
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, false, 0u);
     lane_apply_cap(t, state);

@@ -167,7 +167,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
-        dist.init_process_group("gloo")     # control plane only; the pixels travel over RCCL inside libshray_dist.so
+        # control plane only; the pixels travel over RCCL inside libshray_dist.so.  (gloo reports its connections on the
+        # process's stdout -- "[Gloo] Rank 0 is connected to ..." --, which belongs to rank 0's ONE JSON line: while the
+        # group comes up, file descriptor 1 points at stderr)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     pkg = load_package()
     # rank 0 generates the scene file once; the others wait for it

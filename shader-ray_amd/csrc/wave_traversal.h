@@ -37,9 +37,10 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 // Variants that were built, measured and removed (LDS staging of the top of the tree, MUBUF loads, a DPP combine in the
 // dealt stage, untied register moves, ...): profiles/EXPERIMENTS.md, with their numbers.
 // node visits per lane between two evaluations of inner_stage's exit tests (fewer instructions against more
-// registers; three measured best in round 2, profiles/r02/leaf_stage_ab.txt)
+// registers; three measured best in round 2, four since the visit got shorter in round 4: a lone frame 0.468 -> 0.456 ms,
+// the throughput form +0.2 %, profiles/r04/node_turns_ab.txt)
 #ifndef SHRAY_NODE_TURNS
-#define SHRAY_NODE_TURNS 3
+#define SHRAY_NODE_TURNS 4
 #endif
 
 // Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,

@@ -223,8 +223,8 @@ def test_bench_launches_its_own_ranks(gpu, tmp_path):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--trials", "2",
                           "--width", "640", "--height", "360"], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
-    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, run.stdout
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), run.stdout      # ONE line on stdout: rank 0's (gloo's chatter goes to stderr)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
     assert line["frames_mismatched"] == 0 and line["frames_verified"] >= 8       # a step of 4 frames in each root mode

@@ -88,8 +88,6 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR>;
     Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR>(lds_stack, stack_levels);
-    if (ONE_SAMPLE)
-        trav.keep_dealt = SHRAY_KEEP_WALKING_DEALT_ONE;
     // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
     // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
     // start when the launch is half over (what a lone launch, or the last of a run, then waits for)

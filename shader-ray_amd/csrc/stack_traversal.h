@@ -27,17 +27,14 @@ namespace shray {
 #define SHRAY_KEEP_WALKING 36
 #endif
 constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
-// with the dealt leaf stage a leaf stage with few parked lanes is cheap, so the node loop may yield earlier
+// with the dealt leaf stage a leaf stage with few parked lanes is cheap: the node loop yields as soon as ANY lane is parked
+// (64 of 64).  Measured 48 ... 64 for the one-sample instances on the orbit workload in round 3 (+1.3 % at 64,
+// profiles/r03/dealt_keep_walking_ab.txt) and for the multi-sample dealing instance of the 1M-triangle scene in round 4
+// (40 / 48 / 56 / 64: 2.49 / 2.43 / 2.44 / 2.40 ms, profiles/r04/dealt_keep_walking_ab.txt)
 #ifndef SHRAY_KEEP_WALKING_DEALT
-#define SHRAY_KEEP_WALKING_DEALT 48
+#define SHRAY_KEEP_WALKING_DEALT 64
 #endif
 constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
-// ... and with one ray per pixel it yields as soon as ANY lane is parked (64 of 64: measured 48 ... 64 on the orbit
-// workload, profiles/r03/dealt_keep_walking_ab.txt: +1.3 % throughput at 64, a lone frame no slower); the multi-sample
-// instances (sample lanes: more coherent waves) keep 48
-#ifndef SHRAY_KEEP_WALKING_DEALT_ONE
-#define SHRAY_KEEP_WALKING_DEALT_ONE 64
-#endif
 #ifndef SHRAY_KEEP_FLOOR
 #define SHRAY_KEEP_FLOOR 2
 #endif
@@ -48,7 +45,6 @@ struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
     uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
-    int keep_dealt = kStackKeepWalkingDealt;   // a constant of the instance (kernel_stack.hip sets it before the first traversal)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -107,7 +103,7 @@ struct StackTraversal {
 #endif
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
-            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((DEAL && CONVERGED) ? keep_dealt : kStackKeepWalking) + 32) >> 6);
+            const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
             if (PAIR) {
                 inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);

@@ -143,6 +143,40 @@ def test_hand_built_edge_cases(pkg, gpu, oracle_mod):
         scene.close()
 
 
+def test_triangles_at_the_ends_of_a_leaf_range(pkg, gpu, oracle_mod):
+    """fs:327-331 rejects a candidate outside the range the leaf's box test left.  The kernels park BOUNDS of that range
+    (round 4, wave_traversal.h: visit_decision) and hold a candidate that is about to be accepted within 2^-19 of an end
+    against the exact range: triangles a few 1e-7 in front of, on and behind the near and the far face of a hand-built leaf
+    box -- no inflation, the faces are the triangles' planes -- must be hit or missed exactly as the oracle's divisions say, in
+    the dealt stage (gold, one sample), the plain loop (plaster, two samples) and every other kernel."""
+    from helpers import END, HandScene
+    env = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+
+    def leaf(zs, box_z):
+        tris = [[[-5, -5, z], [5, -5, z], [0, 5, z]] for z in zs]
+        pts = np.asarray(tris, dtype=np.float32).reshape(-1, 3)
+        normals = np.tile(np.asarray([0, 0, 1], np.float32), (len(pts), 1))
+        hm = np.full((8, 1, 2), END, dtype=np.float32)
+        return HandScene(pts, normals, [[-6, -6, box_z[0]]], [[6, 6, box_z[1]]], hm, [[0, len(zs)]], 0)
+
+    near = leaf([1e-5, 3e-6, 1e-6, 3e-7, 1e-7, 0.0, -1e-7, -0.5], (-1.0, 0.0))        # the box's near face is z = 0
+    far = leaf([-1.0 - 1e-6, -1.0 - 3e-7, -1.0 - 1e-7, -1.0, -1.0 + 1e-7], (-1.0, 0.0))  # its far face z = -1
+    only_outside = leaf([1e-4, 2e-5, -1.0 - 2e-5, -1.0 - 1e-4], (-1.0, 0.0))        # beyond the bounds' 2^-20 band: never hit
+    hits = {}
+    for what, hand in (("near face", near), ("far face", far), ("outside only", only_outside)):
+        scene = pkg.Scene(hand.desc, env, device=0)
+        for material, spp in ((0, 1), (6, 2)):
+            for zoom in (3.0, 2.9999998, 7.25):
+                params = default_params(pkg, 48, 32, zoom=zoom, material=material)
+                want = check_against_oracle(oracle_mod, scene, hand.desc, env, params, 48, 32, spp, f"{what} {material} {zoom}")
+                hits[(what, material, zoom)] = float((np.abs(want[..., :3] - want[0, 0, :3]).max(axis=-1) > 1e-6).mean())
+        scene.close()
+    # (the cases are not vacuous: the near- and far-face scenes are hit over most of the frame -- triangles a few 1e-7 outside a
+    # face included, where the ray's own rounding decides --, the scene whose triangles are 2e-5 and more outside never)
+    assert min(v for k, v in hits.items() if k[0] != "outside only" and k[1] == 0) > 0.5
+    assert max(v for k, v in hits.items() if k[0] == "outside only") == 0.0
+
+
 def test_nan_candidates_in_a_dealt_leaf(pkg, gpu, oracle_mod):
     """A triangle whose determinant overflows gives d = u = v = NaN, which fail none of the shader's comparisons
     (raytracer.es.fs:312-340): the sequential loop accepts it and then accepts the next candidate whatever its

@@ -610,23 +610,6 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
     return true;
 }
 
-// One exchange of the dealt stage's combine: every lane looks at the candidate of its partner under DPP control CTRL
-// (all 64 lanes execute; a row is 16 lanes) and keeps the better of the two.
-template <int CTRL>
-__device__ __forceinline__ void combine_dpp(float &best_d, float &best_u, float &best_w, uint32_t &best)
-{
-    const float od = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_d), CTRL, 0xf, 0xf, true));
-    const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)best, CTRL, 0xf, 0xf, true);
-    const float ou = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_u), CTRL, 0xf, 0xf, true));
-    const float ow = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best_w), CTRL, 0xf, 0xf, true));
-    // (bitwise: four comparisons and three mask operations, no branches)
-    const bool take = (ob != 0xffffffffu) & ((best == 0xffffffffu) | (od < best_d) | ((od == best_d) & (ob > best)));
-    best_d = take ? od : best_d;
-    best_u = take ? ou : best_u;
-    best_w = take ? ow : best_w;
-    best = take ? ob : best;
-}
-
 // The search of a dealt stage: `parked` = the lanes in LT_LEAF (K of them, K <= SHRAY_DEAL_MAX_PARKED).  Returns true if
 // a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
 // (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its

@@ -583,7 +583,10 @@ int dispatch_slot_start(shray_scene *scene, shray_scene::DispatchOrder &d, const
             scene->retired.erase(scene->retired.begin() + (long)k);
         }
     }
-    if (!d.cost.p) {
+    if (!d.cost.p || !d.ring.p) {
+        d.cost.release();      // (an earlier allocation that failed half-way leaves nothing behind)
+        d.ring.release();
+        d.capacity = 0;
         // more than a handful set aside: free the ones nobody reads any more (hipFree waits for the device: rare, and only here)
         for (size_t k = 0; scene->retired.size() > 8 && k < scene->retired.size();) {
             if (seq >= scene->retired[k]->retired_at + shray_scene::kBatchSlots)

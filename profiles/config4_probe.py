@@ -11,7 +11,7 @@ pkg = load_package()
 world = pkg.World(helpers.million_obj())
 scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(2048), device=0)
 W, H, spp = 1920, 1080, int(os.environ.get("SPP", "4"))
-params = world.frame_params(W, H, material=0)
+params = world.frame_params(W, H, material=int(os.environ.get("MATERIAL", "0")))
 out = torch.empty(H * W * 4, dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):

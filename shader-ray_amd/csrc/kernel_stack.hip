@@ -16,7 +16,7 @@ bool g_diag_plain_kernel = false;
 // trace_common.h.
 // spp == 1 and a zero diffuse colour get instances without the sample loop / the diffuse branch
 template <bool COUNT, bool ONE_SAMPLE, bool METAL>
-__global__ void __launch_bounds__(kBlock, min_waves(METAL, true)) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_VIEW) trace_stack_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
                                                                                     int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(kBlock, min_waves(METAL, true)) trace_stack_ke
 }
 
 template <bool COUNT, bool DIFF>
-__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_VIEW) trace_stack_view_kernel(SceneView sc, FrameView fr, float4 *out, DeviceCounters *counters,
                                                                                           int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_v
 
 // the debug views, `count` frames per launch: workgroup (x, y) renders patch x of frame y
 template <bool DIFF>
-__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_GENERAL) trace_stack_view_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
+__global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_VIEW) trace_stack_view_batch_kernel(SceneView sc, const FrameView *__restrict__ frames,
                                                                                                 float4 *out, size_t frame_stride, int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];

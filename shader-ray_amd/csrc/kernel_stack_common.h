@@ -23,7 +23,8 @@ constexpr int kBatchBlock = 64;
 // Waves per SIMD the register allocator must leave room for, per class of instance (-D overrides them for A/B builds:
 // `make variant`).  Measured: profiles/r02/leaf_stage_ab.txt, profiles/r03/dealt_occupancy_ab2.txt, profiles/r04/occupancy_ab.txt.
 #ifndef SHRAY_MIN_WAVES
-#define SHRAY_MIN_WAVES 7                 // zero-diffuse instances with the plain leaf loop (<= 72 registers)
+#define SHRAY_MIN_WAVES 8                 // zero-diffuse multi-sample instances with the plain leaf loop (64 registers): config 5's 4K
+                                          // 16 spp frame 10.02 / 9.84 ms at 7 / 8 (10.60 at 6), gold 4 spp +3 % (round 4)
 #endif
 #ifndef SHRAY_MIN_WAVES_DEALT
 #define SHRAY_MIN_WAVES_DEALT 6           // dealt leaf stage, one sample, one frame per launch: a second ray's worth of values (<= 80)
@@ -35,10 +36,17 @@ constexpr int kBatchBlock = 64;
 #define SHRAY_MIN_WAVES_DEALT_MULTI 8     // ... multi-sample (the divergent scenes are latency-bound, every wave is worth its spills:
 #endif                                    // the 1M-triangle scene at 4 spp 2.56 / 2.68 / 2.90 ms at 8 / 7 / 6, round 4)
 #ifndef SHRAY_MIN_WAVES_GENERAL
-#define SHRAY_MIN_WAVES_GENERAL 5         // diffuse / shadow-ray instances with the dealt stage: more state, one wave fewer
+#define SHRAY_MIN_WAVES_GENERAL 7         // diffuse / shadow-ray instances with the dealt stage, one sample: a plaster lone frame 0.700 /
+#endif                                    // 0.688 / 0.675 / 0.683 ms at 5 / 6 / 7 / 8 (round 4: profiles/r04/general_occupancy_ab.txt)
+#ifndef SHRAY_MIN_WAVES_GENERAL_MULTI
+#define SHRAY_MIN_WAVES_GENERAL_MULTI 8   // ... multi-sample (trees larger than an L2 share): the 1M-triangle scene, plaster, 4 spp
+#endif                                    // 4.99 / 4.50 / 4.17 / 4.06 ms at 5 / 6 / 7 / 8
+#ifndef SHRAY_MIN_WAVES_VIEW
+#define SHRAY_MIN_WAVES_VIEW 5            // the shader's debug views and the counting twins (256-thread workgroups, never timed)
 #endif
 #ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN
-#define SHRAY_MIN_WAVES_GENERAL_PLAIN 6   // ... with the plain leaf loop (cache-resident scenes: plaster 8 spp 2.57 -> 2.42 ms, round 2)
+#define SHRAY_MIN_WAVES_GENERAL_PLAIN 7   // ... with the plain leaf loop (cache-resident scenes): config 3 15.87 / 14.69 / 14.43 ms at 5 / 6 / 7,
+                                          // plaster 1 spp 6,649 -> 7,082 Mrays/s at 7 (round 4: profiles/r04/multisample_occupancy_ab.txt)
 #endif
 #ifndef SHRAY_MIN_WAVES_PAIR
 #define SHRAY_MIN_WAVES_PAIR 6
@@ -50,7 +58,7 @@ constexpr int kBatchBlock = 64;
 constexpr int min_waves(bool metal, bool deal, bool one_sample = true)
 {
     return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES)
-                 : (deal ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_PLAIN);
+                 : (deal ? (one_sample ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_MULTI) : SHRAY_MIN_WAVES_GENERAL_PLAIN);
 }
 
 inline bool one_sample(const FrameView &fr) { return fr.spp == 1; }

@@ -492,7 +492,7 @@ unsigned long long dispatch_period()
 bool dispatch_order_enabled()
 {
     static const bool on = [] {
-        const char *e = getenv("1");
+        const char *e = getenv("SHRAY_DISPATCH_ORDER");
         return !(e && e[0] == '0');
     }();
     return on;

@@ -183,11 +183,19 @@ __device__ __forceinline__ void load_packed_node_shared(const SceneView &sc, uin
 {
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
     if (wave_ballot(node != first) == 0ull) {
-        typedef float f8 __attribute__((ext_vector_type(8)));
-        typedef __attribute__((address_space(4))) const f8 constant_f8;
-        const f8 v = *reinterpret_cast<constant_f8 *>(reinterpret_cast<uintptr_t>(sc.packed_nodes) + ((uintptr_t)first << 5));
-        lo = make_float4(v[0], v[1], v[2], v[3]);
-        hi = make_float4(v[4], v[5], v[6], v[7]);
+        typedef unsigned long long q4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(4))) const q4 constant_q4;
+        const q4 v = *reinterpret_cast<constant_q4 *>(reinterpret_cast<uintptr_t>(sc.packed_nodes) + ((uintptr_t)first << 5));
+        // into the lanes' registers two words at a time (v_mov_b64: four moves instead of the eight the compiler makes of it)
+        unsigned long long w0, w1, w2, w3;
+        asm("v_mov_b64 %0, %1" : "=v"(w0) : "s"(v[0]));
+        asm("v_mov_b64 %0, %1" : "=v"(w1) : "s"(v[1]));
+        asm("v_mov_b64 %0, %1" : "=v"(w2) : "s"(v[2]));
+        asm("v_mov_b64 %0, %1" : "=v"(w3) : "s"(v[3]));
+        lo = make_float4(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1),
+                         __uint_as_float((uint32_t)(w1 >> 32)));
+        hi = make_float4(__uint_as_float((uint32_t)w2), __uint_as_float((uint32_t)(w2 >> 32)), __uint_as_float((uint32_t)w3),
+                         __uint_as_float((uint32_t)(w3 >> 32)));
     } else {
         load_packed_node(sc, node, lo, hi);
     }
@@ -233,12 +241,14 @@ __device__ __forceinline__ void slab_range(const LaneTraversal &t, const float4 
 constexpr float kBandUp = 1.0f + 0x1p-20f, kBandDown = 1.0f - 0x1p-20f;       // node test, parked bounds
 constexpr float kCheckUp = 1.0f + 0x1p-19f, kCheckDown = 1.0f - 0x1p-19f;     // leaf_range_check
 
+// (r1 comes back WITHOUT its clamp to kRangeMax: the visit folds the clamp into its three-operand minimum with hit.t, a leaf
+// that is entered applies it to what it parks)
 __device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
     const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
     const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
     r0 = fmaxf(fmaxf(fmaxf(0.0f, ex * t.Y.x), ey * t.Y.y), ez * t.Y.z);
-    r1 = fminf(fminf(fminf(kRangeMax, xx * t.Y.x), xy * t.Y.y), xz * t.Y.z);
+    r1 = fminf(fminf(xx * t.Y.x, xy * t.Y.y), xz * t.Y.z);
 }
 
 // The leaf's exact clipped range (fs:406: the range the leaf's box test left), from the leaf's own record: t.node is
@@ -259,8 +269,8 @@ __device__ __forceinline__ bool near_range_end(float d, float lo0, float hi1) { 
 __device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
     slab_range_fast(t, lo, hi, r0, r1);
-    float below;   // min(r1~, hit.t): one bare v_min_f32 (a NaN hit.t makes its lane divide, so the branch below decides it)
-    asm("v_min_f32 %0, %1, %2" : "=v"(below) : "v"(r1), "v"(t.hit.t));
+    float below;   // min(r1~, 1e8, hit.t): one bare v_min3_f32 (a NaN hit.t makes its lane divide, so the branch below decides it)
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(below) : "v"(r1), "s"(kRangeMax), "v"(t.hit.t));
     const float lo0 = r0 * kBandDown;
     bool enter = r0 * kBandUp < below;
     const bool miss = lo0 >= below;
@@ -300,8 +310,9 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     const bool enter = visit_decision(t, lo, hi, r0, r1);
     if (enter) {
         if (b & kLeafFlag) {
-            // (the leaf's upper bound; a lane that took the exact branch parks a bound 2^-20 above its r1: still a bound)
-            r1 = r1 * kBandUp;
+            // (the leaf's upper bound; a lane that took the exact branch parks a bound 2^-20 above its r1: still a bound;
+            // the clamp slab_range_fast left to its caller: the exact branch's r1 has it already)
+            r1 = fminf(r1, kRangeMax) * kBandUp;
             // the leaf's count word is parked as it is (flag bit and all); the leaf stages clamp it to the leaf cap
             // once per stage (parked_count) instead of every visit masking, clamping and testing it
             const uint32_t count = b;

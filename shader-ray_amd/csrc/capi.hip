@@ -915,9 +915,20 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
                 pt.e1[a] = v[a] - v[6 + a];        // e1 = v0 - v2, raytracer.es.fs:305
             }
         }
-        HIP_TRY(s->packed_nodes.upload(nodes.data(), nodes.size() * sizeof(PackedNode)));
+        {
+            // the device's form of the links (packed_layout.h): byte offsets, the split axis as one of three bits
+            // (2^21 nodes at most -- the float32-index check above -- so an offset stays below 2^26)
+            std::vector<PackedNode> encoded(nodes);
+            for (PackedNode &pn : encoded) {
+                if (pn.b & kLeafFlag)
+                    continue;
+                pn.a = (1u << (kAxisHotShift + (pn.a >> 30))) | ((pn.a & kChildMask) << kNodeShift);
+                pn.b = pn.b << kNodeShift;
+            }
+            HIP_TRY(s->packed_nodes.upload(encoded.data(), encoded.size() * sizeof(PackedNode)));
+        }
         HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
-        s->view.packed_root = packed_root;
+        s->view.packed_root = packed_root << kNodeShift;
         // sibling pairs for the pair traversal: the record of an inner node holds both children's boxes and links.
         // A pair link keeps the child index in kPairIndexMask's 22 bits.  The float32-index check above already bounds
         // a scene at 2^21 nodes (8 link tables x stride <= 2^24); a tree that ever got past that keeps no pair records,

@@ -7,8 +7,12 @@
 //
 //   PackedNode (32 B, depth-first order, negative subtree first)
 //     lo = { boxmin.xyz, a }      hi = { boxmax.xyz, b }
-//     branch: a = (split_axis << 30) | positive_child      b = negative_child
-//     leaf  : a = first triangle                            b = 0x80000000 | count
+//     branch: a = (1 << (29 + split_axis)) | positive_child      b = negative_child
+//     leaf  : a = first triangle                                  b = 0x80000000 | count
+//     A child is named by its BYTE OFFSET in the node array (index * 32: the address of a visit's loads without a shift),
+//     the split axis by one of the three top bits (a ray's "positive direction" bits sit there too: which child comes
+//     first is one AND and one comparison).  shray_scene_create builds the tree with indices and a two-bit axis
+//     (a = axis << 30 | index: what TreeBuilder::pack and the pair records' builder read) and re-encodes it for the device.
 //   PackedTri (36 B, same triangle order as the reference arrays; three 12-byte loads per test)
 //     { v0.xyz } { e0.xyz } { e1.xyz }   e0 = v1 - v0, e1 = v0 - v2
 //     (48-byte records read as three dwordx4 measure 1.5-2 % slower: profiles/r02/leaf_stage_ab.txt)
@@ -66,7 +70,10 @@ constexpr uint32_t kPairIndexMask = 0x003fffffu;
 constexpr uint32_t kPairCountShift = 22, kPairCountMask = 0x7fu, kPairAxisShift = 29;
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
-constexpr uint32_t kChildMask = 0x3fffffffu;
+constexpr uint32_t kChildMask = 0x3fffffffu;         // host form: a = axis << 30 | index
+constexpr uint32_t kChildOffsetMask = 0x1fffffffu;   // device form: a = 1 << (29 + axis) | byte offset
+constexpr uint32_t kAxisHotShift = 29;
+constexpr uint32_t kNodeShift = 5;                   // log2(sizeof(PackedNode))
 constexpr uint32_t kNoNode = 0xffffffffu;
 
 }   // namespace shray

@@ -143,6 +143,7 @@ struct PoolTraversal {
                         t.fy = t.D.y >= 0.0f;
                         t.fz = t.D.z >= 0.0f;
                         t.positive_dir = (t.D.x > 0.0f ? 1u : 0u) | (t.D.y > 0.0f ? 2u : 0u) | (t.D.z > 0.0f ? 4u : 0u);
+                        t.positive_hot = t.positive_dir << kAxisHotShift;
                         busy = true;
                         state = LT_WALK;
                     }

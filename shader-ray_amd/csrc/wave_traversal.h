@@ -70,7 +70,8 @@ struct LaneTraversal {
     bool fx, fy, fz, divide;  // direction signs; divide = operands outside exact_div.h's ranges
     unsigned long long divide_mask;   // the wave's lanes with `divide` set (uniform; kept beside the per-lane flag because a
                               // ballot of a flag that lives in a lane mask is materialised in a vector register first)
-    uint32_t positive_dir;
+    uint32_t positive_dir;    // bit k: D[k] > 0 (the pair traversal's form)
+    uint32_t positive_hot;    // the same three bits at kAxisHotShift, where a node keeps its split axis (packed_layout.h)
     Hit hit;
     uint32_t node;
     uint32_t *top;            // LDS: the next free slot of this ray's stack column (slots are BLOCK words apart)
@@ -118,6 +119,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
     t.fy = D.y >= 0.0f;
     t.fz = D.z >= 0.0f;
     t.positive_dir = (D.x > 0.0f ? 1u : 0u) | (D.y > 0.0f ? 2u : 0u) | (D.z > 0.0f ? 4u : 0u);
+    t.positive_hot = t.positive_dir << kAxisHotShift;
     t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
     t.node = sc.packed_root;
     t.top = stack;
@@ -160,13 +162,13 @@ __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
     }
 }
 
-// A packed node's two 16-byte words.  The address is the (scalar) base plus a 32-bit byte offset, which the load
-// instruction takes as is (SGPR base + VGPR offset): one shift per visit instead of a 64-bit shift-and-add.
-// (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so node and
-// triangle byte offsets stay far below 2^32.)
+// A packed node's two 16-byte words.  `node` is the node's byte offset in the array (packed_layout.h): the address is
+// the (scalar) base plus that 32-bit offset, which the load instruction takes as is (SGPR base + VGPR offset) -- no shift,
+// no 64-bit add.  (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so
+// node and triangle byte offsets stay far below 2^32.)
 __device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
 {
-    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + (node << 5));
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + node);
     lo = p[0];
     hi = p[1];
 }
@@ -185,7 +187,7 @@ __device__ __forceinline__ void load_packed_node_shared(const SceneView &sc, uin
     if (wave_ballot(node != first) == 0ull) {
         typedef unsigned long long q4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(4))) const q4 constant_q4;
-        const q4 v = *reinterpret_cast<constant_q4 *>(reinterpret_cast<uintptr_t>(sc.packed_nodes) + ((uintptr_t)first << 5));
+        const q4 v = *reinterpret_cast<constant_q4 *>(reinterpret_cast<uintptr_t>(sc.packed_nodes) + (uintptr_t)first);
         // into the lanes' registers two words at a time (v_mov_b64: four moves instead of the eight the compiler makes of it)
         unsigned long long w0, w1, w2, w3;
         asm("v_mov_b64 %0, %1" : "=v"(w0) : "s"(v[0]));
@@ -327,9 +329,8 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
             }
             return lane_advance<BLOCK>(t, stack, false, 0u);
         }
-        const uint32_t axis = a >> 30;
-        const uint32_t pos_child = a & kChildMask, neg_child = b;
-        const bool neg_first = (t.positive_dir >> axis) & 1u;
+        const uint32_t pos_child = a & kChildOffsetMask, neg_child = b;
+        const bool neg_first = (a & t.positive_hot) != 0u;     // the node's axis bit against the ray's three
         *t.top = neg_first ? pos_child : neg_child;
         top_move<4 * BLOCK>(t.top);
         return lane_advance<BLOCK>(t, stack, true, neg_first ? neg_child : pos_child);
@@ -875,7 +876,7 @@ __device__ __forceinline__ void retest_stage(const SceneView &sc, LaneTraversal 
         return;
     if (state == LT_RETEST) {
         float4 lo, hi;
-        load_packed_node(sc, t.node & kPairIndexMask, lo, hi);
+        load_packed_node(sc, (t.node & kPairIndexMask) << kNodeShift, lo, hi);
         float r0, r1;
         slab_range(t, lo, hi, r0, r1);
         const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);

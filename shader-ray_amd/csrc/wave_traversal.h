@@ -123,7 +123,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
     t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
     t.node = sc.packed_root;
     t.top = stack;
-    t.left = fr.max_bvh_iterations > 0 ? fr.max_bvh_iterations : -1;   // counted down to the cap; never zero without one
+    t.left = fr.max_bvh_iterations > 0 ? fr.max_bvh_iterations : 0x7fffffff;   // counted down to the cap; never zero without one
     t.leaf_cap = (uint32_t)fr.max_leaf_tests;
     asm volatile("" : "+s"(t.leaf_cap));
     if (COUNT && counted)
@@ -148,15 +148,21 @@ __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, b
 }
 
 // The cap of fs:426-438: a ray that has just used its last visit and is not finished becomes a bad hit
-// (set_bad_hit).  `left` reaches zero exactly there (lane_begin starts it at -1 when there is no cap, and it stays
-// zero in a ray that was capped, for which the store below is idempotent), so the test is one comparison per visit
-// and the rare store is skipped by the whole wave -- instead of a compare and two selects in each branch of the visit.
+// (set_bad_hit).  `left` reaches zero exactly there (lane_begin starts it at 2^31 - 1 when there is no cap), so the test is
+// one comparison and the rare store is skipped by the whole wave -- instead of a compare and two selects in each branch
+// of the visit.  The timed instances make the comparison once per SHRAY_NODE_TURNS visits (inner_stage): a lane that has
+// used its last visit walks on for up to SHRAY_NODE_TURNS - 1 more -- visits change neither its hit nor anything another
+// lane sees, its stack stays within the tree's depth -- and `left` goes on down, hence `<= 0`; whatever state that leaves
+// the lane in (walking, parked in a leaf whose triangles are then never tested, finished), it ends here as a bad hit.
+// A comparison per visit is 1.7 % of the headline (profiles/r04/cap_check_ab.txt).  The counting twins compare at every
+// visit: their tallies are the reference's.
 __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
 {
-    if (__builtin_expect(__builtin_amdgcn_uicmp((unsigned int)t.left, 0u, 32 /* eq */) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_sicmp(t.left, 0, 41 /* sle */) != 0ull, 0)) {
         asm volatile("; iteration cap" ::: "memory");   // keeps this a branch (the compiler would predicate three moves into every visit)
-        if (t.left == 0) {
+        if (t.left <= 0) {
             t.hit.t = -1.0f;
+            t.left = 0;
             state = LT_ENDED;
         }
     }
@@ -477,8 +483,11 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                 SHRAY_DIAG_WAIT(4);
                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
             }
-            lane_apply_cap(t, state);
+            if (COUNT)
+                lane_apply_cap(t, state);
         }
+        if (!COUNT)
+            lane_apply_cap(t, state);
         const int walking = __popcll(wave_ballot(state == LT_WALK));
         if (walking < keep_walking && (wave_ballot(state == LT_LEAF) || others_waiting))
             return;

@@ -162,11 +162,14 @@ struct PoolTraversal {
 #pragma unroll
                     for (int turn = 0; turn < 2; turn++) {
                         if (state == LT_WALK) {
-                            float4 lo, hi;
-                            load_packed_node(sc, t.node, lo, hi);
-                            state = lane_visit_loaded<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
+                            lane_count_visit(t);
+                            lane_apply_cap(t, state);     // (at every visit: a capped ray must not travel to another wave)
+                            if (state == LT_WALK) {
+                                float4 lo, hi;
+                                load_packed_node(sc, t.node, lo, hi);
+                                state = lane_visit_loaded<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
+                            }
                         }
-                        lane_apply_cap(t, state);
                     }
                     turns += 2;
                     const int walking = __popcll(wave_ballot(state == LT_WALK));

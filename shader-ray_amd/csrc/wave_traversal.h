@@ -130,8 +130,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
         rc.traversals++;
 }
 
-// A node visit (with its triangles, if any) is over: follow the link.  Returns the lane's next state; the
-// iteration cap (fs:426-438) is applied by lane_apply_cap, which every caller runs next.
+// A node visit (with its triangles, if any) is over: follow the link.  Returns the lane's next state.
 template <int BLOCK>
 __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, bool descended, uint32_t near_child)
 {
@@ -143,26 +142,27 @@ __device__ __forceinline__ int lane_advance(LaneTraversal &t, uint32_t *stack, b
         top_move<-4 * BLOCK>(t.top);
         t.node = *t.top;
     }
-    t.left--;
-    return LT_WALK;
+    return LT_WALK;             // (the visit this leads to is counted where it is made: lane_count_visit)
 }
 
-// The cap of fs:426-438: a ray that has just used its last visit and is not finished becomes a bad hit
-// (set_bad_hit).  `left` reaches zero exactly there (lane_begin starts it at 2^31 - 1 when there is no cap), so the test is
-// one comparison and the rare store is skipped by the whole wave -- instead of a compare and two selects in each branch
-// of the visit.  The timed instances make the comparison once per SHRAY_NODE_TURNS visits (inner_stage): a lane that has
-// used its last visit walks on for up to SHRAY_NODE_TURNS - 1 more -- visits change neither its hit nor anything another
-// lane sees, its stack stays within the tree's depth -- and `left` goes on down, hence `<= 0`; whatever state that leaves
-// the lane in (walking, parked in a leaf whose triangles are then never tested, finished), it ends here as a bad hit.
-// A comparison per visit is 1.7 % of the headline (profiles/r04/cap_check_ab.txt).  The counting twins compare at every
-// visit: their tallies are the reference's.
+// The cap of fs:426-438: a ray that has used max_bvh_iterations visits and is not finished becomes a bad hit (set_bad_hit).
+// A visit is counted where it is made, by ONE subtraction in front of the node's fetch (counted where the previous visit
+// moved on, the subtraction sat on both of that visit's paths -- descend, pop -- and a wave whose lanes take both issued it
+// twice): `left` goes below zero on the visit that is one too many.
+//   * The counting twins test there and do not make that visit: their tallies are the reference's.
+//   * The timed instances test once per SHRAY_NODE_TURNS visits (inner_stage: lane_apply_cap): a lane that is past its last
+//     visit walks on for up to SHRAY_NODE_TURNS more -- visits change neither its hit nor anything another lane sees, its
+//     stack stays within the tree's depth --; whatever state that leaves it in (walking, parked in a leaf whose triangles
+//     are then never tested, finished), it ends as the bad hit it became.  A comparison per visit is 1.7 % of the headline
+//     (profiles/r04/cap_check_ab.txt).
+__device__ __forceinline__ void lane_count_visit(LaneTraversal &t) { t.left--; }
+
 __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
 {
-    if (__builtin_expect(__builtin_amdgcn_sicmp(t.left, 0, 41 /* sle */) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_sicmp(t.left, 0, 40 /* slt */) != 0ull, 0)) {
         asm volatile("; iteration cap" ::: "memory");   // keeps this a branch (the compiler would predicate three moves into every visit)
-        if (t.left <= 0) {
+        if (t.left < 0) {
             t.hit.t = -1.0f;
-            t.left = 0;
             state = LT_ENDED;
         }
     }
@@ -477,14 +477,17 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
         for (int turn = 0; turn < SHRAY_NODE_TURNS; turn++) {   // the exit tests below run once per SHRAY_NODE_TURNS visits
             SHRAY_DIAG_COUNT(0);
             if (state == LT_WALK) {
-                SHRAY_DIAG_T0
-                float4 lo, hi;
-                load_packed_node_shared(sc, t.node, lo, hi);
-                SHRAY_DIAG_WAIT(4);
-                state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+                lane_count_visit(t);
+                if (COUNT)
+                    lane_apply_cap(t, state);
+                if (!COUNT || state == LT_WALK) {
+                    SHRAY_DIAG_T0
+                    float4 lo, hi;
+                    load_packed_node_shared(sc, t.node, lo, hi);
+                    SHRAY_DIAG_WAIT(4);
+                    state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
+                }
             }
-            if (COUNT)
-                lane_apply_cap(t, state);
         }
         if (!COUNT)
             lane_apply_cap(t, state);
@@ -559,7 +562,6 @@ __device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &
     }
     if (state == LT_LEAF)
         state = lane_advance<BLOCK>(t, stack, false, 0u);
-    lane_apply_cap(t, state);
 }
 
 template <bool COUNT, int BLOCK, bool PAIR = false>

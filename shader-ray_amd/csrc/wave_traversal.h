@@ -320,7 +320,9 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
         if (b & kLeafFlag) {
             // (the leaf's upper bound; a lane that took the exact branch parks a bound 2^-20 above its r1: still a bound;
             // the clamp slab_range_fast left to its caller: the exact branch's r1 has it already)
-            r1 = fminf(r1, kRangeMax) * kBandUp;
+            // (a bare v_min_f32: fminf() canonicalises its operand first, one more instruction)
+            asm("v_min_f32 %0, %1, %0" : "+v"(r1) : "s"(kRangeMax));
+            r1 = r1 * kBandUp;
             // the leaf's count word is parked as it is (flag bit and all); the leaf stages clamp it to the leaf cap
             // once per stage (parked_count) instead of every visit masking, clamping and testing it
             const uint32_t count = b;

@@ -547,6 +547,23 @@ def main():
             roof["vector_memory"] = vmem
             roof["valu_issue"] = {"achieved": roof.get("achieved"), "peak": VALU_PEAK_GINST, "frac": roof.get("frac"), "unit": "Gwaveinst/s",
                                   "busy_frac_profiled": round(pmc["valu_busy_frac_profiled"], 4) if pmc and pmc.get("valu_busy_frac_profiled") else None}
+            # `frac` prices every vector instruction at the peak's 2 cycles.  Only f32 add / sub / mul, 32-bit integer add and
+            # logic, register moves and VCC selects issue at that rate; fma, min / max, compares, other selects and anything
+            # with a scalar-register operand take 4, transcendentals 8 (profiles/r04/valu_costs_probe.txt).  From the mix the
+            # hardware counts (one more --pmc pass of the same command): the VALU's busy fraction lies between "only what is
+            # counted as fma / transcendental is slow" and "only what is counted as f32 add / mul is fast"
+            mix = pmc.get("valu_mix_per_launch") if pmc else None
+            if mix and pmc.get("valu_insts_per_launch") and roof.get("frac"):
+                total = pmc["valu_insts_per_launch"]
+                fast_sure = mix.get("add_f32", 0.0) + mix.get("mul_f32", 0.0)
+                fma, trans = mix.get("fma_f32", 0.0), mix.get("trans_f32", 0.0)
+                lo = (2.0 * (total - fma - trans) + 4.0 * fma + 8.0 * trans) / (2.0 * total)
+                hi = (2.0 * fast_sure + 8.0 * trans + 4.0 * (total - fast_sure - trans)) / (2.0 * total)
+                roof["valu_issue"].update({
+                    "frac_class_weighted": [round(roof["frac"] * lo, 4), round(roof["frac"] * hi, 4)],
+                    "mix_of_vector_instructions": {k: round(v / total, 4) for k, v in mix.items()},
+                    "frac_class_weighted_is": "frac x (cycles per instruction by class / 2): lower bound with only the counted fma and "
+                                              "transcendental instructions at 4 and 8 cycles, upper bound with only the counted f32 add / mul at 2"})
             # The headline pair names the busier pipe.  Compared in ONE run, the profiled one (rocprofv3 runs a launch at a time
             # while it counts: there a four-frame launch has the GPU to itself and every pipe is less busy than in the timed
             # loop, whose launches overlap): VALU = 2 cycles x SQ_INSTS_VALU / (1024 SIMDs x the kernel's cycles), the vector
@@ -560,6 +577,23 @@ def main():
                                  "frac_is": f"the {stage} stage's busy fraction in the profiled run (VALU in the same run: "
                                             f"{pmc['valu_busy_frac_profiled']:.3f}); achieved = frac x the peak measured in this run; "
                                             "the timed loop's VALU fraction is valu_issue.frac"})
+            # The fractions above are of the PROFILED run, where rocprofv3 runs one launch at a time (a four-frame launch alone:
+            # serialized_launch_ms).  The timed loop overlaps launches and finishes a frame sooner; the work a frame hands each
+            # pipe is the same, so the pipe's busy fraction in the timed loop is its busy cycles per frame over the timed
+            # loop's cycles per frame (at the clock the profiled launches ran at): an estimate, reported beside the measurement
+            if pmc and pmc.get("serialized_launch_ms") and pmc.get("serialized_clock_ghz"):
+                fpl = pmc["workload"].get("frames_per_launch", 1)
+                # (the launch's own cycles, GRBM_GUI_ACTIVE / 8 -- what the profiled fractions are fractions of --, at that clock)
+                serial_ms = pmc["kernel_cycles_profiled"] / pmc["serialized_clock_ghz"] / 1e6 / fpl
+                scale = serial_ms / (elapsed / args.steps * 1e3)
+                est = {"serialized_ms_per_frame": round(serial_ms, 5), "clock_ghz": round(pmc["serialized_clock_ghz"], 3),
+                       "is": "profiled busy fraction x (profiled time per frame / timed time per frame): same work per frame, less time"}
+                for key, name in (("td_busy_frac", "texture_data_busy"), ("ta_busy_frac", "texture_addresser_busy")):
+                    if pmc.get(key):
+                        est[name] = round(pmc[key] * scale, 4)
+                if roof["valu_issue"].get("frac_class_weighted"):
+                    est["valu_busy_class_weighted"] = roof["valu_issue"]["frac_class_weighted"]
+                roof["timed_loop_estimate"] = est
             roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                          "concurrent_launches": lanes, "frames_per_launch": batch,
                          "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed (every {EVENT_STRIDE}th)"})

@@ -31,6 +31,28 @@ nxt = re.search(r"\n(?=\S)", block[1:])
 block = block if not nxt else block[:nxt.start() + 1]
 vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+n=\s*\d+\s+avg\s+([\d.]+)", block, re.M)}
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
+
+
+def serialized_launch():
+    """(median duration in ms of the kernel's launches in the counter passes -- rocprofv3 runs one dispatch at a time while it
+    counts --, the clock GRBM_GUI_ACTIVE / 8 XCDs ticks at over those launches in GHz), from the pass that counted
+    GRBM_GUI_ACTIVE; (None, None) when the per-dispatch files are not beside the summary."""
+    import csv
+    import glob
+    import statistics
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(summary_path), "pmc*", "*", "*counter_collection.csv"))):
+        per = {}
+        for r in csv.DictReader(open(path)):
+            if want in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                per[r["Dispatch_Id"]] = (float(r["Counter_Value"]) / 8.0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if per:
+            ns = statistics.median(d for _, d in per.values())
+            ghz = statistics.median(c / d for c, d in per.values() if d > 0)
+            return ns / 1e6, ghz
+    return None, None
+
+
+serial_ms, serial_ghz = serialized_launch()
 out = {
     "kernel": want,
     "workload": {"width": 1920, "height": 1080, "spp": 1, "material": 0, "kernel_id": 0, "frames_per_launch": frames_per_launch,
@@ -53,6 +75,12 @@ out = {
     "ta_busy_frac": (vals["TA_TA_BUSY_sum"] / 256.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "TA_TA_BUSY_sum" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
     "td_busy_frac": (vals["TD_TD_BUSY_sum"] / 256.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "TD_TD_BUSY_sum" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
     "valu_busy_frac_profiled": (vals["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0)) if "SQ_INSTS_VALU" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
+    # the mix of vector instructions by the classes the hardware counts (profiles/r04/valu_costs_probe.txt: f32 add / sub / mul
+    # issue one per 2 cycles, fma one per 4, transcendentals one per 8; what is in none of the five -- min / max, compares,
+    # selects, moves, conversions -- is of either class)
+    "valu_mix_per_launch": {k[len("SQ_INSTS_VALU_"):].lower(): vals[k] for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                            "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32") if k in vals} or None,
+    "serialized_launch_ms": serial_ms, "serialized_clock_ghz": serial_ghz,
     "kernel_cycles_profiled": (vals["GRBM_GUI_ACTIVE"] / 8.0) if vals.get("GRBM_GUI_ACTIVE") else None,
     "wait_frac": (vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in vals and vals.get("SQ_WAVE_CYCLES") else None,
     "source": summary_path,

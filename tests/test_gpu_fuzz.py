@@ -129,3 +129,49 @@ def test_random_soup(pkg, gpu, oracle_mod, tmp_path, seed, kind):
                 assert counters == cpu, f"{what}, kernel {kernel}: counters {counters} != oracle {cpu}"
     finally:
         scene.close()
+
+
+@pytest.mark.parametrize("seed,kind", CASES[:len(CASES) * 3 // 5])
+def test_random_soup_in_frame_batches(pkg, gpu, oracle_mod, tmp_path, seed, kind):
+    """The same soups through shray_render_batch_device (the instances the bench's frame loop runs: several frames per launch,
+    whole frames and tile sets), every frame against the oracle."""
+    import torch
+    N = pkg._native
+    rng = np.random.default_rng(5000 + seed)
+    pos, tri = soup(rng, kind)
+    path = os.path.join(tmp_path, f"soup{seed}.obj")
+    pkg.scenes.write_obj(path, pos, tri)
+    world = pkg.World(path)
+    desc = world.flatten()
+    env = pkg.scenes.environment_hdr_sky(256, seed=seed)
+    scene = pkg.Scene(desc, env, device=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for spp, all_metal in ((1, True), (1, False), (3, True), (4, False)):
+            W, H = [(96, 64), (61, 47), (128, 40)][int(rng.integers(0, 3))]
+            cap = int(rng.choice([400, 400, 60, 17]))
+            frames = []
+            for k in range(int(rng.integers(2, 6))):
+                material = 0 if all_metal else int(rng.choice([0, 6, 5]))
+                p = world.frame_params(W, H, random_view(rng, world), material=material)
+                p.max_bvh_iterations = cap
+                p.bounce_count = int(rng.choice([2, 3]))
+                frames.append(p)
+            want = [oracle_mod.render(desc, env, p, W, H, spp)[0] for p in frames]
+            for tiles in (None, N.TileSet(32, 32, 3, int(rng.integers(0, 3)))):
+                nbytes = pkg.tracer.tile_buffer_bytes(W, H, tiles)
+                got = torch.zeros(len(frames), nbytes // 4, dtype=torch.float32, device="cuda:0")
+                scene.render_batch_into(frames, W, H, spp, got.data_ptr(), nbytes, stream, tiles)
+                torch.cuda.synchronize()
+                for k, p in enumerate(frames):
+                    if tiles is None:
+                        frame = got[k].cpu().numpy().reshape(H, W, 4)
+                        differing = int((frame.view(np.uint32) != want[k].view(np.uint32)).sum())
+                        assert differing == 0, f"seed {seed} {kind} spp {spp} cap {cap} frame {k} of {len(frames)}: {differing} floats differ"
+                    else:
+                        one = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda:0")
+                        scene.render_into(p, W, H, spp, one.data_ptr(), stream, tiles)
+                        torch.cuda.synchronize()
+                        assert torch.equal(got[k], one), f"seed {seed} {kind} spp {spp} tile set, frame {k}"
+    finally:
+        scene.close()

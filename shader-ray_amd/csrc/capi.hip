@@ -916,19 +916,33 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
             }
         }
         {
-            // the device's form of the links (packed_layout.h): byte offsets, the split axis as one of three bits
-            // (2^21 nodes at most -- the float32-index check above -- so an offset stays below 2^26)
-            std::vector<PackedNode> encoded(nodes);
-            for (PackedNode &pn : encoded) {
-                if (pn.b & kLeafFlag)
-                    continue;
-                pn.a = (1u << (kAxisHotShift + (pn.a >> 30))) | ((pn.a & kChildMask) << kNodeShift);
-                pn.b = pn.b << kNodeShift;
+            // the device's form (packed_layout.h): one copy per direction octant, holding a box as the planes a ray of that
+            // octant enters and leaves it by and a branch's children in the order it visits them, named by byte offset / 8
+            // (2^21 nodes at most -- the float32-index check above -- so the eight copies end below 2^29 bytes)
+            const size_t n = nodes.size();
+            std::vector<PackedNode> copies(n * 8);
+            for (uint32_t o = 0; o < 8; o++) {
+                PackedNode *c = copies.data() + (size_t)o * n;
+                for (size_t k = 0; k < n; k++) {
+                    PackedNode pn = nodes[k];
+                    for (int axis = 0; axis < 3; axis++)
+                        if (!((o >> axis) & 1u))
+                            std::swap(pn.lo[axis], pn.hi[axis]);
+                    if (!(pn.b & kLeafFlag)) {
+                        const uint32_t axis = pn.a >> 30, pos = (pn.a & kChildMask) << (kNodeShift - kNodeNameShift),
+                                       neg = pn.b << (kNodeShift - kNodeNameShift);
+                        const bool negative_first = (o >> axis) & 1u;     // D[axis] > 0 (a zero component: visit_decision)
+                        pn.a = (1u << (kAxisHotShift + axis)) | (negative_first ? neg : pos);
+                        pn.b = negative_first ? pos : neg;
+                    }
+                    c[k] = pn;
+                }
             }
-            HIP_TRY(s->packed_nodes.upload(encoded.data(), encoded.size() * sizeof(PackedNode)));
+            HIP_TRY(s->packed_nodes.upload(copies.data(), copies.size() * sizeof(PackedNode)));
+            s->view.packed_nodes_bytes = (uint32_t)(n * sizeof(PackedNode));
         }
         HIP_TRY(s->packed_tris.upload(tris.data(), tris.size() * sizeof(PackedTri)));
-        s->view.packed_root = packed_root << kNodeShift;
+        s->view.packed_root = packed_root << (kNodeShift - kNodeNameShift);
         // sibling pairs for the pair traversal: the record of an inner node holds both children's boxes and links.
         // A pair link keeps the child index in kPairIndexMask's 22 bits.  The float32-index check above already bounds
         // a scene at 2^21 nodes (8 link tables x stride <= 2^24); a tree that ever got past that keeps no pair records,

@@ -33,9 +33,10 @@ struct SceneView {
     uint32_t triangle_count;
     float tree_root;
 
-    const void *packed_nodes;   // PackedNode[group_count]
+    const void *packed_nodes;   // PackedNode[8][group_count]: one copy per direction octant (packed_layout.h)
+    uint32_t packed_nodes_bytes;   // of one copy
     const void *packed_tris;    // PackedTri[triangle_count]
-    uint32_t packed_root;
+    uint32_t packed_root;       // the root's name (packed_layout.h: byte offset / 8)
     uint32_t exact_div_ok;      // every box coordinate is 0 or in [2^-70, 2^60): exact_div.h applies
     const void *pair_nodes;     // PackedPair[group_count] (packed_layout.h), or nullptr: the pair traversal is not available
     uint32_t pair_root_link;    // the root as a pair link: index | axis << 29 | leaf flag

@@ -5,14 +5,23 @@
 // is repacked so that one node visit is two 16-byte loads and one triangle
 // test is three, and the eight link tables collapse into "push the far child":
 //
-//   PackedNode (32 B, depth-first order, negative subtree first)
+//   PackedNode (32 B, depth-first order, negative subtree first), as the host builds it:
 //     lo = { boxmin.xyz, a }      hi = { boxmax.xyz, b }
-//     branch: a = (1 << (29 + split_axis)) | positive_child      b = negative_child
-//     leaf  : a = first triangle                                  b = 0x80000000 | count
-//     A child is named by its BYTE OFFSET in the node array (index * 32: the address of a visit's loads without a shift),
-//     the split axis by one of the three top bits (a ray's "positive direction" bits sit there too: which child comes
-//     first is one AND and one comparison).  shray_scene_create builds the tree with indices and a two-bit axis
-//     (a = axis << 30 | index: what TreeBuilder::pack and the pair records' builder read) and re-encodes it for the device.
+//     branch: a = split_axis << 30 | positive_child      b = negative_child       (indices)
+//     leaf  : a = first triangle                          b = 0x80000000 | count
+//   On the device the array exists EIGHT times, once per direction octant (round 4; bit k of an octant: D[k] >= 0, the
+//   predicate range_intersect_box picks a box's entry plane by, fs:204-213).  Copy o holds, node for node at the same offset,
+//     lo = { the planes a ray of octant o ENTERS the box by, a' }     hi = { the planes it LEAVES by, b' }
+//     branch: a' = 1 << (29 + split_axis) | name of the child such a ray visits FIRST      b' = name of the other child
+//     leaf  : as above
+//   where a node's NAME is its byte offset in a copy / 8 (below 2^23: shray_scene_create admits 2^21 nodes).  A ray reads
+//   the copy of its own octant -- lanes of one wave read different copies -- so a visit selects nothing: not the six
+//   planes (six v_cndmask), not the child (an AND, a compare, two more v_cndmask); its record's address is
+//   (name << 3) + octant * bytes-per-copy, one instruction, the shift dropping the axis bit of a'.  The reference orders the
+//   children by D[axis] > 0 (world.cpp:259-265 with get_coded_dir, :214-220); that and D[axis] >= 0 differ for a component
+//   that is zero, which the visit corrects on the path its division takes anyway (wave_traversal.h: visit_decision).
+//   Eight copies cost memory (bunny-class: 8 x 0.64 MB; the 1M-triangle scene: 8 x 9.3 MB) and bought 2.4 ... 3.4 % on every
+//   BASELINE configuration, that one included (profiles/r04/octant_copies_ab.txt).
 //   PackedTri (36 B, same triangle order as the reference arrays; three 12-byte loads per test)
 //     { v0.xyz } { e0.xyz } { e1.xyz }   e0 = v1 - v0, e1 = v0 - v2
 //     (48-byte records read as three dwordx4 measure 1.5-2 % slower: profiles/r02/leaf_stage_ab.txt)
@@ -71,8 +80,9 @@ constexpr uint32_t kPairCountShift = 22, kPairCountMask = 0x7fu, kPairAxisShift 
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kChildMask = 0x3fffffffu;         // host form: a = axis << 30 | index
-constexpr uint32_t kChildOffsetMask = 0x1fffffffu;   // device form: a = 1 << (29 + axis) | byte offset
+constexpr uint32_t kChildNameMask = 0x1fffffffu;     // device form: a' = 1 << (29 + axis) | name (byte offset / 8)
 constexpr uint32_t kAxisHotShift = 29;
+constexpr uint32_t kNodeNameShift = 3;               // name -> byte offset
 constexpr uint32_t kNodeShift = 5;                   // log2(sizeof(PackedNode))
 constexpr uint32_t kNoNode = 0xffffffffu;
 

@@ -143,7 +143,7 @@ struct PoolTraversal {
                         t.fy = t.D.y >= 0.0f;
                         t.fz = t.D.z >= 0.0f;
                         t.positive_dir = (t.D.x > 0.0f ? 1u : 0u) | (t.D.y > 0.0f ? 2u : 0u) | (t.D.z > 0.0f ? 4u : 0u);
-                        t.positive_hot = t.positive_dir << kAxisHotShift;
+                        t.octant = octant_offset(sc, t.fx, t.fy, t.fz);
                         busy = true;
                         state = LT_WALK;
                     }
@@ -166,7 +166,7 @@ struct PoolTraversal {
                             lane_apply_cap(t, state);     // (at every visit: a capped ray must not travel to another wave)
                             if (state == LT_WALK) {
                                 float4 lo, hi;
-                                load_packed_node(sc, t.node, lo, hi);
+                                load_packed_node(sc, node_address(t, t.node), lo, hi);
                                 state = lane_visit_loaded<COUNT, BLOCK>(fr, t, column, rc, lo, hi);
                             }
                         }

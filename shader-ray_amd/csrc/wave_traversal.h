@@ -71,7 +71,9 @@ struct LaneTraversal {
     unsigned long long divide_mask;   // the wave's lanes with `divide` set (uniform; kept beside the per-lane flag because a
                               // ballot of a flag that lives in a lane mask is materialised in a vector register first)
     uint32_t positive_dir;    // bit k: D[k] > 0 (the pair traversal's form)
-    uint32_t positive_hot;    // the same three bits at kAxisHotShift, where a node keeps its split axis (packed_layout.h)
+    uint32_t octant;          // byte offset of the copy of the node array this ray's visits read: the one whose records hold the
+                              // planes a ray of its direction octant enters and leaves a box by, and the children in the
+                              // order it visits them (packed_layout.h)
     Hit hit;
     uint32_t node;
     uint32_t *top;            // LDS: the next free slot of this ray's stack column (slots are BLOCK words apart)
@@ -94,6 +96,16 @@ __device__ __forceinline__ void top_move(uint32_t *&top)
     asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(p) : "i"((unsigned int)BYTES));
     top = (uint32_t *)p;
 }
+
+// The copy of the node array a ray reads (packed_layout.h: one per direction octant; bit k of the octant = D[k] >= 0, the
+// predicate range_intersect_box selects a box's entry plane by, fs:204-213), as a byte offset; and the address of a visit's
+// record in it.  A ray names a node by its byte offset / 8 with the node's split axis in the three bits above (the word the
+// parent's record holds): the address is ONE instruction, (node << 3) + octant -- the shift drops the axis bits.
+__device__ __forceinline__ uint32_t octant_offset(const SceneView &sc, bool fx, bool fy, bool fz)
+{
+    return ((fx ? 1u : 0u) | (fy ? 2u : 0u) | (fz ? 4u : 0u)) * sc.packed_nodes_bytes;
+}
+__device__ __forceinline__ uint32_t node_address(const LaneTraversal &t, uint32_t node) { return (node << kNodeNameShift) + t.octant; }
 
 // group_intersect set-up for the object-space ray (P, D)                      (fs:388-392, :486)
 template <bool COUNT>
@@ -119,7 +131,7 @@ __device__ __forceinline__ void lane_begin(const SceneView &sc, const FrameView 
     t.fy = D.y >= 0.0f;
     t.fz = D.z >= 0.0f;
     t.positive_dir = (D.x > 0.0f ? 1u : 0u) | (D.y > 0.0f ? 2u : 0u) | (D.z > 0.0f ? 4u : 0u);
-    t.positive_hot = t.positive_dir << kAxisHotShift;
+    t.octant = octant_offset(sc, t.fx, t.fy, t.fz);
     t.hit = Hit{kFar, -1.0f, 0.0f, 0.0f};
     t.node = sc.packed_root;
     t.top = stack;
@@ -168,18 +180,18 @@ __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
     }
 }
 
-// A packed node's two 16-byte words.  `node` is the node's byte offset in the array (packed_layout.h): the address is
-// the (scalar) base plus that 32-bit offset, which the load instruction takes as is (SGPR base + VGPR offset) -- no shift,
-// no 64-bit add.  (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so
-// node and triangle byte offsets stay far below 2^32.)
-__device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t node, float4 &lo, float4 &hi)
+// A packed node's two 16-byte words.  `at` is the record's byte offset in the eight copies (node_address): the address is
+// the (scalar) base plus that 32-bit offset, which the load instruction takes as is (SGPR base + VGPR offset) -- no 64-bit
+// add.  (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so the eight
+// copies end below 2^29 bytes and triangle byte offsets stay far below 2^32.)
+__device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t at, float4 &lo, float4 &hi)
 {
-    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + node);
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + at);
     lo = p[0];
     hi = p[1];
 }
 
-// The same for the lanes of a wave that are executing, when they are all at ONE node (the top of the tree, coherent primary
+// The same for the lanes of a wave that are executing, when they are all at ONE record (one node, one octant: the top of the tree, coherent primary
 // rays: 51 % of the headline's wave-visits, profiles/r04/distinct_nodes_per_wave_visit.txt).  A CU's vector memory
 // pipeline -- one per CU, shared by its four SIMDs -- spends about 14 cycles on a 16-byte-per-lane instruction whatever its
 // lanes read, even with one lane active (profiles/r04/vector_cache_probe.json), and that pipeline is what bounds the node
@@ -212,10 +224,15 @@ __device__ __forceinline__ void load_packed_node_shared(const SceneView &sc, uin
 // range_intersect_box of the node's box against [0, 1e8] (fs:200-217, :272-275): the entry plane is the box's low
 // side when D >= 0, else its high side.  The arithmetic the shader demands of a node visit: 6 selects, 6 subtractions,
 // 6 quotients, 6 min / max (profiles/isa_costs.py counts it in isolation).
+// PRESELECTED: (lo, hi) is a record of the ray's octant copy -- its entry planes, its exit planes: the selects were made when
+// the scene was created.  (The pair traversal's records hold the scene's boxes as they are: it selects.)
+template <bool PRESELECTED = true>
 __device__ __forceinline__ void slab_range(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
-    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
-    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    const float ex = ((PRESELECTED || t.fx) ? lo.x : hi.x) - t.P.x, ey = ((PRESELECTED || t.fy) ? lo.y : hi.y) - t.P.y,
+                ez = ((PRESELECTED || t.fz) ? lo.z : hi.z) - t.P.z;
+    const float xx = ((PRESELECTED || t.fx) ? hi.x : lo.x) - t.P.x, xy = ((PRESELECTED || t.fy) ? hi.y : lo.y) - t.P.y,
+                xz = ((PRESELECTED || t.fz) ? hi.z : lo.z) - t.P.z;
     // all six quotients are finite on this path, so hardware min/max equal GLSL's select forms
     // (the residuals of the reciprocals are wanted HERE only, in a branch the wave rarely takes; computed from values the
     // optimizer can see are loop-invariant they are hoisted in front of the node loop and spilled there -- three scratch
@@ -251,10 +268,11 @@ constexpr float kCheckUp = 1.0f + 0x1p-19f, kCheckDown = 1.0f - 0x1p-19f;     //
 
 // (r1 comes back WITHOUT its clamp to kRangeMax: the visit folds the clamp into its three-operand minimum with hit.t, a leaf
 // that is entered applies it to what it parks)
+// (lo = the entry planes, hi = the exit planes of the ray's octant: no select)
 __device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
-    const float ex = (t.fx ? lo.x : hi.x) - t.P.x, ey = (t.fy ? lo.y : hi.y) - t.P.y, ez = (t.fz ? lo.z : hi.z) - t.P.z;
-    const float xx = (t.fx ? hi.x : lo.x) - t.P.x, xy = (t.fy ? hi.y : lo.y) - t.P.y, xz = (t.fz ? hi.z : lo.z) - t.P.z;
+    const float ex = lo.x - t.P.x, ey = lo.y - t.P.y, ez = lo.z - t.P.z;
+    const float xx = hi.x - t.P.x, xy = hi.y - t.P.y, xz = hi.z - t.P.z;
     r0 = fmaxf(fmaxf(fmaxf(0.0f, ex * t.Y.x), ey * t.Y.y), ez * t.Y.z);
     r1 = fminf(fminf(xx * t.Y.x, xy * t.Y.y), xz * t.Y.z);
 }
@@ -264,7 +282,7 @@ __device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const fl
 __device__ __forceinline__ void exact_leaf_range(const SceneView &sc, const LaneTraversal &t, float &e0, float &e1)
 {
     float4 lo, hi;
-    load_packed_node(sc, t.node, lo, hi);
+    load_packed_node(sc, node_address(t, t.node), lo, hi);
     slab_range(t, lo, hi, e0, e1);
 }
 
@@ -274,7 +292,10 @@ __device__ __forceinline__ bool near_range_end(float d, float lo0, float hi1) { 
 
 // fs:400's decision for one visit; r0 = a lower bound of the box's entry distance, r1 = an approximation of its exit
 // distance within 2^-22 (or both exact, from the branch): see above.
-__device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
+// (a, b: the record's two link words -- a branch's children in the order the octant visits them; a lane whose direction has a
+// ZERO component corrects that order here, see below)
+__device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1,
+                                               uint32_t &a, uint32_t &b)
 {
     slab_range_fast(t, lo, hi, r0, r1);
     float below;   // min(r1~, 1e8, hit.t): one bare v_min3_f32 (a NaN hit.t makes its lane divide, so the branch below decides it)
@@ -295,6 +316,20 @@ __device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const flo
             slab_range(t, lo, hi, r0, r1);
             enter = !(r0 >= r1) && (r0 < t.hit.t);
         }
+        // The children's order.  The reference descends into the negative child first when the direction component along
+        // the split axis is > 0 (world.cpp:259-265, :214-220), and takes a box's low plane as its entry plane when it is
+        // >= 0 (fs:204-213): one octant copy serves both except for a component that IS zero (+0 or -0), whose copy holds
+        // the order of a positive one.  Such a lane divides (zero is outside exact_div.h's range) and so is always here:
+        // it swaps the words back.
+        if (t.divide && !(b & kLeafFlag)) {
+            const uint32_t zero_axes = (t.D.x == 0.0f ? 1u << kAxisHotShift : 0u) | (t.D.y == 0.0f ? 2u << kAxisHotShift : 0u) |
+                                       (t.D.z == 0.0f ? 4u << kAxisHotShift : 0u);
+            if (a & zero_axes) {
+                const uint32_t first = a & kChildNameMask;
+                a = (a & ~kChildNameMask) | b;
+                b = first;
+            }
+        }
     }
 #endif
     return enter;
@@ -310,12 +345,12 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
 {
     if (COUNT)
         rc.node_visits++;
-    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
+    uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
     if (COUNT && (b & kLeafFlag))
         rc.leaf_visits++;   // the reference fetches (start, count) before the box test, fs:263-267
 
     float r0, r1;
-    const bool enter = visit_decision(t, lo, hi, r0, r1);
+    const bool enter = visit_decision(t, lo, hi, r0, r1, a, b);
     if (enter) {
         if (b & kLeafFlag) {
             // (the leaf's upper bound; a lane that took the exact branch parks a bound 2^-20 above its r1: still a bound;
@@ -337,11 +372,11 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
             }
             return lane_advance<BLOCK>(t, stack, false, 0u);
         }
-        const uint32_t pos_child = a & kChildOffsetMask, neg_child = b;
-        const bool neg_first = (a & t.positive_hot) != 0u;     // the node's axis bit against the ray's three
-        *t.top = neg_first ? pos_child : neg_child;
+        // a = the child this ray's octant visits first (under the split axis' bit, which node_address() shifts out), b = the
+        // other one: nothing to decide
+        *t.top = b;
         top_move<4 * BLOCK>(t.top);
-        return lane_advance<BLOCK>(t, stack, true, neg_first ? neg_child : pos_child);
+        return lane_advance<BLOCK>(t, stack, true, a);
     }
     return lane_advance<BLOCK>(t, stack, false, 0u);
 }
@@ -351,7 +386,7 @@ __device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &
                                           RayCounters &rc)
 {
     float4 lo, hi;
-    load_packed_node(sc, t.node, lo, hi);
+    load_packed_node(sc, node_address(t, t.node), lo, hi);
     return lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
 }
 
@@ -485,7 +520,7 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                 if (!COUNT || state == LT_WALK) {
                     SHRAY_DIAG_T0
                     float4 lo, hi;
-                    load_packed_node_shared(sc, t.node, lo, hi);
+                    load_packed_node_shared(sc, node_address(t, t.node), lo, hi);
                     SHRAY_DIAG_WAIT(4);
                     state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
                 }
@@ -843,8 +878,8 @@ __device__ __forceinline__ int lane_pair_turn(const SceneView &sc, LaneTraversal
             rc.leaf_visits++;
     }
     float n0, n1, f0, f1;
-    slab_range(t, nlo, nhi, n0, n1);
-    slab_range(t, flo, fhi, f0, f1);
+    slab_range<false>(t, nlo, nhi, n0, n1);
+    slab_range<false>(t, flo, fhi, f0, f1);
     *t.top = pair_stack_word(far_link, f0, !(f0 >= f1), sc.pair_index_bits);
     t.top += BLOCK;
     if (!(n0 >= n1) && (n0 < t.hit.t)) {
@@ -889,9 +924,10 @@ __device__ __forceinline__ void retest_stage(const SceneView &sc, LaneTraversal 
         return;
     if (state == LT_RETEST) {
         float4 lo, hi;
-        load_packed_node(sc, (t.node & kPairIndexMask) << kNodeShift, lo, hi);
+        // (the node's own record, from the copy that holds the scene's boxes as they are: the last one)
+        load_packed_node(sc, ((t.node & kPairIndexMask) << kNodeShift) + 7u * sc.packed_nodes_bytes, lo, hi);
         float r0, r1;
-        slab_range(t, lo, hi, r0, r1);
+        slab_range<false>(t, lo, hi, r0, r1);
         const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
         state = LT_ENDED;              // placeholder: decided below
         bool entered = false;

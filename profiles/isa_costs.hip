@@ -41,7 +41,8 @@ __global__ void cost_node(const float *rays, const float4 *nodes, float *out)
     for (int k = 0; k < REPS; k++) {
         const float4 lo = nodes[(2u * i + 0u) + 4096u * k], hi = nodes[(2u * i + 1u) + 4096u * k];
         float r0, r1;
-        const bool enter = visit_decision(t, lo, hi, r0, r1);
+        uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
+        const bool enter = visit_decision(t, lo, hi, r0, r1, a, b);   // (lo, hi: a record of the ray's octant copy: no selects)
         out[i + 65536u * k] = enter ? r0 : r1;
     }
 }

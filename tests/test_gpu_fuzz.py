@@ -80,7 +80,10 @@ def random_view(rng, world):
     view = world.default_view()
     axis = rng.normal(0, 1, 3)
     axis /= np.linalg.norm(axis)
-    view.object_rotation[:] = [float(rng.uniform(0, 2 * math.pi)), *axis.astype(float)]
+    # one view in four leaves the object un-rotated: the rays of a frame of odd width / height then include directions with
+    # components that are exactly zero (the centre column and row; true division, and the children's order for D[axis] == 0)
+    angle = 0.0 if rng.integers(0, 4) == 0 else float(rng.uniform(0, 2 * math.pi))
+    view.object_rotation[:] = [angle, *axis.astype(float)]
     axis = rng.normal(0, 1, 3)
     axis /= np.linalg.norm(axis)
     view.light_rotation[:] = [float(rng.uniform(0, 2 * math.pi)), *axis.astype(float)]

@@ -159,11 +159,14 @@ __global__ void cost_primary_and_tonemap(const FrameView *frames, const float *r
     const FrameView &fr = frames[0];
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float fw = (float)fr.width, fh = (float)fr.height;
+    // (as uniform_driver.h makes them: the divisors' reciprocals once, outside the count of one repetition)
+    const SharedDivisor by_width = shared_divisor(fw), by_height = shared_divisor(fh);
+    const bool eye_in_range = magnitude_in(fr.image_plane_width, -30, 8) && magnitude_in(fr.aspect, -30, 8);
 #pragma unroll
     for (int k = 0; k < REPS; k++) {
         const float *r = rays + 16u * i + 1048576u * k;
-        const float u = (r[0] + 0.5f) / fw, v = (r[1] + 0.5f) / fh;
-        const V3 eye = unit(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f));
+        const float u = divide_by_shared(r[0] + 0.5f, by_width), v = divide_by_shared(r[1] + 0.5f, by_height);
+        const V3 eye = unit_of_eye(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f), eye_in_range);
         const V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
         const V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
         float *o = out + 16u * i + 1048576u * k;

@@ -70,4 +70,32 @@ __device__ __forceinline__ bool divisor_in_range(float b) { return magnitude_in(
 __device__ __forceinline__ bool reciprocal_domain(float x) { return magnitude_in(x, -100, 99); }
 __device__ __forceinline__ bool coordinate_in_range(float c) { return c == 0.0f || magnitude_in(c, -70, 59); }
 
+// A divisor many dividends share (a frame's width and height): RN(1 / b) and its residual once, then div_by_constant4's four
+// operations per quotient instead of the compiler's eleven -- when b is inside the proven range and the CALLER vouches for
+// the dividends (0, or a magnitude in [2^-93, 2^61]); otherwise the true division.  `b` is wave-uniform where this is used,
+// so `exact` is a scalar and the choice a scalar branch.
+struct SharedDivisor {
+    float b, y, yl;
+    bool exact;
+};
+__device__ __forceinline__ SharedDivisor shared_divisor(float b)
+{
+    SharedDivisor d;
+    d.b = b;
+    d.exact = divisor_in_range(b);
+    d.y = reciprocal_in_range(b);           // (not looked at when b is outside the range)
+    d.yl = reciprocal_residual(b, d.y);
+    return d;
+}
+__device__ __forceinline__ float divide_by_shared(float a, const SharedDivisor &d)
+{
+#ifndef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes
+    if (__builtin_expect(!d.exact, 0)) {
+        asm volatile("; a shared divisor outside exact_div.h's range" ::: "memory");   // keeps this a branch
+        return a / d.b;
+    }
+#endif
+    return div_by_constant4(a, d.b, d.y, d.yl);
+}
+
 }   // namespace shray

@@ -126,6 +126,22 @@ __device__ __forceinline__ V3 interpolated_normal(const SceneView &sc, bool fp16
     return mk(n[0], n[1], n[2]) * bw + mk(n[3], n[4], n[5]) * bu + mk(n[6], n[7], n[8]) * bv;
 }
 
+// REPEAT wrap of a texel index: (i % n, made non-negative) for EVERY int i and n >= 1.  A remainder by a divisor that is not a
+// compile-time constant is ~28 vector instructions, and a lookup makes four; the lookup's own coordinates (s in [1/2, 3/2],
+// t in [0, 1]) put i in [-n, 2n), where the remainder is one conditional subtraction and the fix-up one conditional addition.
+// Anything else (the filtered view's probes, coordinates that are not numbers) takes the remainders, in ONE branch the wave skips.
+__device__ __forceinline__ int wrap_near(int i, int n)
+{
+    const int r = i >= n ? i - n : i;
+    return r < 0 ? r + n : r;
+}
+__device__ __forceinline__ bool wrap_is_near(int i, int n) { return (unsigned int)i + (unsigned int)n < 3u * (unsigned int)n; }   // -n <= i < 2n
+__device__ __forceinline__ int wrap_any(int i, int n)
+{
+    const int r = i % n;
+    return r < 0 ? r + n : r;
+}
+
 // LINEAR lookup with REPEAT wrap in one level of the environment pyramid
 __device__ __forceinline__ V3 environment_level(const float *texels, int w, int h, float s, float t)
 {
@@ -133,12 +149,20 @@ __device__ __forceinline__ V3 environment_level(const float *texels, int w, int 
     const float v = t * (float)h - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
-    int i0 = (int)fu % w, j0 = (int)fv % h;
-    int i1 = (int)(fu + 1.0f) % w, j1 = (int)(fv + 1.0f) % h;
-    i0 += i0 < 0 ? w : 0;
-    i1 += i1 < 0 ? w : 0;
-    j0 += j0 < 0 ? h : 0;
-    j1 += j1 < 0 ? h : 0;
+    const int iu0 = (int)fu, iu1 = (int)(fu + 1.0f), iv0 = (int)fv, iv1 = (int)(fv + 1.0f);
+    int i0 = wrap_near(iu0, w), i1 = wrap_near(iu1, w), j0 = wrap_near(iv0, h), j1 = wrap_near(iv1, h);
+#ifndef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes
+    const bool far = !(wrap_is_near(iu0, w) && wrap_is_near(iu1, w) && wrap_is_near(iv0, h) && wrap_is_near(iv1, h));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(far) != 0ull, 0)) {
+        asm volatile("; a texel index outside [-n, 2n): the remainders" ::: "memory");   // keeps this a branch
+        if (far) {
+            i0 = wrap_any(iu0, w);
+            i1 = wrap_any(iu1, w);
+            j0 = wrap_any(iv0, h);
+            j1 = wrap_any(iv1, h);
+        }
+    }
+#endif
     const float *r0 = texels + 3 * (size_t)j0 * w;
     const float *r1 = texels + 3 * (size_t)j1 * w;
     const V3 t00 = mk(r0[3 * i0], r0[3 * i0 + 1], r0[3 * i0 + 2]);

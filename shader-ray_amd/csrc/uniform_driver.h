@@ -29,6 +29,23 @@ namespace shray {
 // (shray_render_counters_timed).
 // ORDERED: the launch reads a dispatch order and its waves report their running times (capi.hip: DispatchOrder) -- an
 // instance of its own, because the two scalars it carries through the kernel cost the others 2 % (12 B more scratch)
+// unit() of the eye-space ray (x, y, -1): three quotients by one length.  components_in_range (uniform): see the caller; the
+// length itself is checked here (a lane far outside the frame could have an absurd one); the wave takes the true divisions
+// unless every lane qualifies -- the two forms give the same quotients wherever both apply.
+__device__ __forceinline__ V3 unit_of_eye(V3 a, bool components_in_range)
+{
+    const float length = sqrtf(dot3(a, a));
+    const bool exact = components_in_range && divisor_in_range(length);
+#ifndef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!exact) != 0ull, 0)) {
+        asm volatile("; an eye ray outside exact_div.h's ranges" ::: "memory");   // keeps this a branch
+        return a / length;
+    }
+#endif
+    const float y = reciprocal_in_range(length), yl = reciprocal_residual(length, y);
+    return mk(div_by_constant4(a.x, length, y, yl), div_by_constant4(a.y, length, y, yl), div_by_constant4(a.z, length, y, yl));
+}
+
 template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false, bool ORDERED = false>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool,
@@ -85,8 +102,15 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     const V3 spec = mk(fr.specular_color[0], fr.specular_color[1], fr.specular_color[2]);
     const V3 diff = mk(fr.diffuse_color[0], fr.diffuse_color[1], fr.diffuse_color[2]);
     const bool has_diffuse = !METAL && diff.x > 0.0f && diff.y > 0.0f && diff.z > 0.0f;   // fs:570, uniform
-    const float fw = (float)fr.width, fh = (float)fr.height, fn = (float)fr.spp;
+    // (a ONE_SAMPLE instance is launched for spp == 1 only: its divisions by the sample count fold away)
+    const float fw = (float)fr.width, fh = (float)fr.height, fn = ONE_SAMPLE ? 1.0f : (float)fr.spp;
     const int samples = ONE_SAMPLE ? 1 : fr.spp;
+    // the pixel coordinates' divisions by the frame's width and height (vs:39-60): dividends px + ox, py + oy are 0 or of
+    // magnitude in [2^-25, 2^25) -- a pixel index plus an offset in (0, 1] --, the divisors shared by the whole launch
+    const SharedDivisor by_width = shared_divisor(fw), by_height = shared_divisor(fh);
+    // the eye ray's normalization: its length is at least 1 (the -1 component) and its components are 0 or no smaller than
+    // 2^-85 when the image plane's width and the aspect ratio are ordinary numbers (u - 0.5 is 0 or at least 2^-25)
+    const bool eye_in_range = magnitude_in(fr.image_plane_width, -30, 8) && magnitude_in(fr.aspect, -30, 8);
 
     V3 sum = mk(0, 0, 0);
     float channel_sum = 0.0f, channel_sum2 = 0.0f;   // sample lanes: this lane's colour channel (lane 0 of a pair: also blue)
@@ -96,9 +120,9 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         // primary ray (vs:39-60, fs:619), sub-pixel pattern of the oracle
         const float ox = ((float)s + 0.5f) / fn;
         const float oy = (float)__brev((unsigned int)s) * 2.3283064365386963e-10f + 0.5f / fn;
-        const float u = ((float)px + ox) / fw;
-        const float v = ((float)py + oy) / fh;
-        const V3 eye = unit(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f));
+        const float u = divide_by_shared((float)px + ox, by_width);
+        const float v = divide_by_shared((float)py + oy, by_height);
+        const V3 eye = unit_of_eye(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f), eye_in_range);
         V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
         V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
 

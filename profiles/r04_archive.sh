@@ -3,6 +3,7 @@
 R=profiles/r04
 cp gpurun_out/prof_r04_default/summary.txt $R/default_bench_command_summary.txt
 cp gpurun_out/prof_r04_config4/summary.txt $R/config4_4spp_summary.txt
+for t in config3 config5 lone_frame; do [ -e gpurun_out/prof_r04_$t/summary.txt ] && cp gpurun_out/prof_r04_$t/summary.txt $R/${t}_summary.txt; done
 f=$(ls -t gpurun_out/prof_r04_default/trace/runc/*_kernel_stats.csv | head -1); [ -n "$f" ] && cp "$f" $R/r04_default_kernel_stats.csv
 cp gpurun_out/bench_default.json gpurun_out/bench_steps20.json gpurun_out/bench_same_view.json gpurun_out/bench_dist1.json gpurun_out/bench_gloo3.json \
    gpurun_out/vector_cache_probe.json gpurun_out/scene_turnaround.json $R/

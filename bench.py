@@ -42,7 +42,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WIDTH, HEIGHT, SPP = 1920, 1080, 1
 ORBIT = 20                 # distinct views of the orbit; frame k of a run is view k % ORBIT
@@ -148,7 +147,6 @@ def main():
     import torch.distributed as dist
 
     from __graft_entry__ import load_package
-    import helpers
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,10 +182,10 @@ def main():
     pkg = load_package()
     # rank 0 generates the scene file once; the others wait for it
     if rank == 0:
-        path = helpers.bunny_trisrc()
+        path = pkg.scenes.bunny_trisrc()
     if distributed:
         dist.barrier()
-    path = helpers.bunny_trisrc()
+    path = pkg.scenes.bunny_trisrc()
     t_load = time.perf_counter()
     world = pkg.World(path)
     t_flatten = time.perf_counter()

@@ -153,12 +153,16 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
 
 /* After a step on `buffer_set` (and once hip_stream has reached that point): the frames this rank assembled.
  * *assembled frames, the k-th of them frame *first_frame + k * *frame_step of the step, RGBA float32 row 0 = bottom,
- * at *d_rgba + k * width * height * 16 (device memory owned by the object). */
+ * at *d_rgba + k * width * height * 16 (device memory owned by the object).  The set's next step overwrites that memory:
+ * whoever reads through the raw pointer orders the reads before that step himself (same stream, or an event the step's
+ * stream waits for); shray_dist_copy_output does it for its copy. */
 int shray_dist_output(shray_dist *dist, int buffer_set, int count, int *assembled, int *first_frame, int *frame_step,
                       void **d_rgba);
 
 /* Enqueues on hip_stream a copy of those assembled frames, back to back, into d_dst (device memory on this
- * rank's device, *assembled * width * height * 16 bytes) -- e.g. a buffer of the application's own. */
+ * rank's device, *assembled * width * height * 16 bytes) -- e.g. a buffer of the application's own.  hip_stream may be any
+ * stream: the copy waits (on the device) for the step that wrote the frames, and the set's next step -- on whichever
+ * stream -- waits for the copy. */
 int shray_dist_copy_output(shray_dist *dist, int buffer_set, int count, void *d_dst, void *hip_stream);
 
 /* For CALLBACK transports written where no HIP binding is at hand (the Python / gloo rehearsal): a blocking copy of

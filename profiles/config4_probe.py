@@ -6,9 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from __graft_entry__ import load_package
-import helpers
 pkg = load_package()
-world = pkg.World(helpers.million_obj())
+world = pkg.World(pkg.scenes.million_obj())
 scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(2048), device=0)
 W, H, spp = 1920, 1080, int(os.environ.get("SPP", "4"))
 params = world.frame_params(W, H, material=int(os.environ.get("MATERIAL", "0")))

@@ -6,10 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from __graft_entry__ import load_package
-import helpers
 pkg = load_package()
 million = os.environ.get("SCENE", "bunny") == "million"
-world = pkg.World(helpers.million_obj() if million else helpers.bunny_trisrc())
+world = pkg.World(pkg.scenes.million_obj() if million else pkg.scenes.bunny_trisrc())
 scene = pkg.Scene(world.flatten(), pkg.scenes.environment_hdr_sky(2048), device=0)
 W, H, spp = int(os.environ.get("WIDTH", "1920")), int(os.environ.get("HEIGHT", "1080")), int(os.environ.get("SPP", "1"))
 material = int(os.environ.get("MATERIAL", "0"))

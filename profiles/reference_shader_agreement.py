@@ -14,7 +14,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from __graft_entry__ import load_package  # noqa: E402
-import helpers  # noqa: E402
 import oracle  # noqa: E402
 
 pkg = load_package()
@@ -24,10 +23,10 @@ constant = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
 print("reference shaders: raytracer.vs + raytracer.es.fs, '#version 140', anisotropy 1 (see tests/test_reference_shader.py); "
       "oracle: oracle/shader_oracle.cpp; relative difference per pixel = max over R, G, B of |a - b| / max(|b|, 1e-2)")
 for what, path, env, env_name, material in (
-        ("configs[1]: bunny-class mesh, gold", helpers.bunny_trisrc(), sky, "HDR sky 2048x1024", 0),
-        ("configs[2] at 1 spp: bunny-class mesh, glazed plaster (shadow rays)", helpers.bunny_trisrc(), sky, "HDR sky 2048x1024", 6),
-        ("configs[1] with a constant environment (no texture filter in the way)", helpers.bunny_trisrc(), constant, "constant", 0),
-        ("configs[3] at 1 spp: 1M-triangle OBJ, gold", helpers.million_obj(), constant, "constant", 0)):
+        ("configs[1]: bunny-class mesh, gold", pkg.scenes.bunny_trisrc(), sky, "HDR sky 2048x1024", 0),
+        ("configs[2] at 1 spp: bunny-class mesh, glazed plaster (shadow rays)", pkg.scenes.bunny_trisrc(), sky, "HDR sky 2048x1024", 6),
+        ("configs[1] with a constant environment (no texture filter in the way)", pkg.scenes.bunny_trisrc(), constant, "constant", 0),
+        ("configs[3] at 1 spp: 1M-triangle OBJ, gold", pkg.scenes.million_obj(), constant, "constant", 0)):
     world = pkg.World(path)
     desc = world.flatten()
     params = world.frame_params(W, H, material=material)

@@ -11,7 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from __graft_entry__ import load_package
-import helpers
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KERNEL = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -48,14 +47,14 @@ def run(name, world, scene, params, W, H, spp, reps):
 
 
 t0 = time.time()
-bunny = pkg.World(helpers.bunny_trisrc())
+bunny = pkg.World(pkg.scenes.bunny_trisrc())
 scene = pkg.Scene(bunny.flatten(), env, device=0)
 run("1: 256x256 primary rays only (parity anchor)", bunny, scene, (lambda p: (setattr(p, "bounce_count", 1), p)[1])(bunny.frame_params(256, 256, material=0)), 256, 256, 1, 200)
 run("2: 1920x1080 1 spp gold (headline)", bunny, scene, bunny.frame_params(1920, 1080, material=0), 1920, 1080, 1, 100)
 run("3: 1920x1080 64 spp glazed plaster", bunny, scene, bunny.frame_params(1920, 1080, material=6), 1920, 1080, 64, 3)
 run("5 (one GPU's view): 3840x2160 16 spp gold, whole frame on one GPU", bunny, scene, bunny.frame_params(3840, 2160, material=0), 3840, 2160, 16, 3)
 scene.close()
-big = pkg.World(helpers.million_obj())
+big = pkg.World(pkg.scenes.million_obj())
 print("1M-triangle scene loaded: %d triangles, %d nodes, depth %d (%.1f s since start)" % (
     big.triangle_count, big.info.node_count, big.info.max_level, time.time() - t0), flush=True)
 scene = pkg.Scene(big.flatten(), env, device=0)

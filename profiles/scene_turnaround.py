@@ -13,11 +13,10 @@ import json, os, sys, time
 sys.path[:0] = [%r, %r]
 import torch
 from __graft_entry__ import load_package
-import helpers
 pkg = load_package()
 torch.zeros(1, device="cuda")
 rows = []
-for name, path in (("bunny-class trisrc", helpers.bunny_trisrc()), ("1M-triangle obj", helpers.million_obj())):
+for name, path in (("bunny-class trisrc", pkg.scenes.bunny_trisrc()), ("1M-triangle obj", pkg.scenes.million_obj())):
     best = None
     for rep in range(3):
         t0 = time.perf_counter(); world = pkg.World(path)

@@ -26,13 +26,12 @@ def main():
     args = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime)
     from __graft_entry__ import load_package
-    import helpers
     pkg = load_package()
     N = pkg._native
     N.HIP_LIB = os.environ.get("SHRAY_DIAG_LIB") or os.path.join(N.PKG_DIR, "libshray_hip_diag.so")
     lib = N.load_hip()
     lib.shray_debug_timeline.restype = C.c_int
-    world = pkg.World(helpers.million_obj() if args.million else helpers.bunny_trisrc())
+    world = pkg.World(pkg.scenes.million_obj() if args.million else pkg.scenes.bunny_trisrc())
     desc = world.flatten()
     scene = pkg.Scene(desc, pkg.scenes.environment_hdr_sky(2048), device=0)
     scene.set_kernel(args.kernel)

@@ -904,7 +904,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         uint32_t packed_root = 0;
         tb.pack(nodes, &packed_root);
         const size_t nt = nv / 3;
-        std::vector<PackedTri> tris(nt);
+        std::vector<PackedTri> tris(nt + 1);   // a spare record: the leaf cache fetches a leaf in 16-byte chunks (wave_traversal.h)
         for (size_t t = 0; t < nt; t++) {
             const float *v = desc->vertex_positions + 9 * t;
             PackedTri &pt = tris[t];

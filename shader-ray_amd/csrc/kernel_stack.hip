@@ -20,8 +20,9 @@ __global__ void __launch_bounds__(kBlock, SHRAY_MIN_WAVES_VIEW) trace_stack_kern
                                                                                     int stack_levels)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    StackTraversal<kBlock, true> trav = make_traversal<true>(lds_stack, stack_levels);
-    trace_pixels_uniform<StackTraversal<kBlock, true>, COUNT, ONE_SAMPLE, METAL>(sc, fr, out, counters, trav);
+    using Traversal = StackTraversal<kBlock, true, false, caches_leaves(false)>;
+    Traversal trav = make_traversal<true, kBlock, false, caches_leaves(false)>(lds_stack, stack_levels);
+    trace_pixels_uniform<Traversal, COUNT, ONE_SAMPLE, METAL>(sc, fr, out, counters, trav);
 }
 
 template <bool COUNT, bool DIFF>
@@ -78,6 +79,8 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     // the throughput form of the headline workload deals its leaves too, at its own occupancy (trace_stack_batch_dense_kernel)
     b.dense = b.one && b.metallic && !deal && !pair && all_plain;
     b.ordered = ordered;
+    if (!view_instance)
+        b.lds_bytes = stack_lds_bytes(stack_levels, kBatchBlock, caches_leaves(pair));
     if (view_instance) {
         if (first.which == 1 || first.which == 2)
             hipLaunchKernelGGL(trace_stack_view_batch_kernel<true>, b.grid, b.block, b.lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels);
@@ -99,7 +102,7 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
                         hipStream_t stream, int stack_levels)
 {
     const dim3 grid(fr.total_patches), block(kBlock);
-    const size_t lds_bytes = stack_lds_bytes(stack_levels);
+    const size_t lds_bytes = stack_lds_bytes(stack_levels, kBlock, plain_view(fr) && caches_leaves(false));
 #define SHRAY_LAUNCH(K) hipLaunchKernelGGL((K), grid, block, lds_bytes, stream, sc, fr, out, counters, stack_levels)
     if (!counters)
         return hipErrorInvalidValue;

@@ -68,18 +68,24 @@ inline bool metal(const FrameView &fr)
 }
 inline bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which == 2 || fr.which == 3 || fr.which == 5); }
 
-inline size_t stack_lds_bytes(int stack_levels, int block = kBlock)
+#ifndef SHRAY_LDS_PAD
+#define SHRAY_LDS_PAD 0u   // unused LDS per wave (occupancy experiments)
+#endif
+// the batch instances whose sequential leaf loop reads its triangles from the wave's leaf cache in LDS (wave_traversal.h)
+constexpr bool caches_leaves(bool pair) { return SHRAY_LEAF_CACHE != 0 && !pair; }
+
+inline size_t stack_lds_bytes(int stack_levels, int block = kBlock, bool cache = false)
 {
-    // stack columns + the dealt leaf stage's id tables (64 bytes per wave)
-    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)block;
+    // stack columns + per wave: the dealt leaf stage's id table (64 bytes) and, in the instances that have one, the leaf cache
+    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)(block / 64) * (kIdsBytes + (cache ? kCacheBytes : 0u) + SHRAY_LDS_PAD);
 }
 
-template <bool DEAL, int BLOCK = kBlock, bool PAIR = false>
-__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR> make_traversal(uint32_t *lds, int stack_levels)
+template <bool DEAL, int BLOCK = kBlock, bool PAIR = false, bool CACHE = false>
+__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR, CACHE> make_traversal(uint32_t *lds, int stack_levels)
 {
-    StackTraversal<BLOCK, DEAL, PAIR> trav;
+    StackTraversal<BLOCK, DEAL, PAIR, CACHE> trav;
     trav.stack = lds + threadIdx.x;
-    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x & ~63u);
+    trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x >> 6) * (kIdsBytes + (CACHE ? kCacheBytes : 0u));
     return trav;
 }
 
@@ -94,8 +100,8 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
                                                  int stack_levels, int frame_count_arg, DeviceCounters *counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR>;
-    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR>(lds_stack, stack_levels);
+    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR, caches_leaves(PAIR)>;
+    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR, caches_leaves(PAIR)>(lds_stack, stack_levels);
     // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
     // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
     // start when the launch is half over (what a lone launch, or the last of a run, then waits for)

@@ -176,7 +176,7 @@ struct PoolTraversal {
                     if ((walking < keep && wave_ballot(state == LT_LEAF)) || turns >= kPoolEpochTurns)
                         break;
                 }
-                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, column, rc SHRAY_DIAG_ARG);
+                leaf_stage<COUNT, BLOCK>(sc, fr, t, state, column, rc, nullptr SHRAY_DIAG_ARG);
             }
 
             // ---- a ray that ended in this epoch leaves its hit in the first four levels of its own column

@@ -40,7 +40,8 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #endif
 // DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
 // PAIR: both children of a node per turn (wave_traversal.h: inner_stage_pair); convergent form only
-template <int BLOCK, bool DEAL = true, bool PAIR = false>
+// CACHE: the sequential leaf loop reads a stage's distinct leaves from the wave's LDS slab (wave_traversal.h: leaf cache; `ids` is followed by it)
+template <int BLOCK, bool DEAL = true, bool PAIR = false, bool CACHE = false>
 struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
@@ -98,7 +99,7 @@ struct StackTraversal {
     __device__ __forceinline__ void run(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state, RayCounters &rc)
     {
         do {
-#ifdef SHRAY_DIAGNOSTICS
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
@@ -109,16 +110,16 @@ struct StackTraversal {
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);
             } else
                 inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
-#ifdef SHRAY_DIAGNOSTICS
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
             if (DEAL && CONVERGED)
-                leaf_stage_dealt<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
+                leaf_stage_dealt<COUNT, BLOCK, PAIR, CACHE>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             else
-                leaf_stage<COUNT, BLOCK, PAIR>(sc, fr, t, state, stack, rc SHRAY_DIAG_ARG);
+                leaf_stage<COUNT, BLOCK, PAIR, CACHE>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             if (ANY_HIT && state != LT_ENDED && t.hit.t < kFar)
                 state = LT_ENDED;   // a hit: the shadow query is answered (a capped ray, t = -1, has ended already)
-#ifdef SHRAY_DIAGNOSTICS
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
             const unsigned long long c2 = __builtin_amdgcn_s_memtime();
             diag_tally[2] += c1 - c0;
             diag_tally[3] += c2 - c1;

@@ -46,7 +46,22 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 // Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
 // cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
 
-#ifdef SHRAY_DIAGNOSTICS
+// SHRAY_DIAG_KHIST (with SHRAY_DIAGNOSTICS; profiles/leaf_stage_histogram.py): the eight tallies are instead a histogram of
+// the dealt leaf stages by the number of parked lanes K -- bins K = 1, 2, 3-4, 5-8, 9-16, 17-32, > 32 (the plain loop) --,
+// each word {stages, bits 0-23; rounds of three strided fetches the stage runs, bits 24-43; 16-byte-per-lane fetches a
+// stage would run if every group fetched its leaf's bytes as consecutive chunks, bits 44-63}; nothing is timed.
+#if defined(SHRAY_DIAGNOSTICS) && defined(SHRAY_DIAG_KHIST)
+#ifndef SHRAY_DIAG_KHIST_FROM
+#define SHRAY_DIAG_KHIST_FROM 32
+#endif
+#define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SHRAY_DIAG_T0
+#define SHRAY_DIAG_WAIT(k) ((void)0)
+#define SHRAY_DIAG_COUNT(k) ((void)0)
+#define SHRAY_DIAG_PARAM , unsigned long long *diag_tally_ref
+#define SHRAY_DIAG_ARG , diag_tally
+#define SHRAY_DIAG_ARG_FWD , diag_tally_ref
+#elif defined(SHRAY_DIAGNOSTICS)
 #define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SHRAY_DIAG_T0 const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
 #define SHRAY_DIAG_WAIT(k) do { __builtin_amdgcn_s_waitcnt(0); diag_tally_ref[k] += __builtin_amdgcn_s_memtime() - diag_t0; } while (0)
@@ -484,14 +499,19 @@ __device__ __forceinline__ void lane_test_triangle_loaded(const SceneView &sc, L
 struct PackedF3 {
     float x, y, z;
 };
+__device__ __forceinline__ void load_packed_triangle_at(const SceneView &sc, uint32_t byte_offset, float4 &q0, float4 &q1, float4 &q2);
 __device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
+{
+    load_packed_triangle_at(sc, index * 36u, q0, q1, q2);
+}
+__device__ __forceinline__ void load_packed_triangle_at(const SceneView &sc, uint32_t byte_offset, float4 &q0, float4 &q1, float4 &q2)
 {
     // base + 32-bit byte offset, as for the nodes
     // 36 bytes as 16 + 16 + 4 (what the back end makes of three 12-byte loads anyway), pinned as the register tuples the
     // loads fill: pinned component by component, every test began with five or six moves out of those tuples
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef f4 __attribute__((aligned(4), may_alias)) packed_f4;
-    const char *p = reinterpret_cast<const char *>(sc.packed_tris) + index * 36u;
+    const char *p = reinterpret_cast<const char *>(sc.packed_tris) + byte_offset;
     f4 a = *reinterpret_cast<const packed_f4 *>(p), b = *reinterpret_cast<const packed_f4 *>(p + 16);
     float c = *reinterpret_cast<const float *>(p + 32);
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
@@ -546,7 +566,7 @@ __device__ __forceinline__ uint32_t parked_count(uint32_t leaf_count, uint32_t l
 template <bool COUNT, bool BOUNDS>
 __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
 {
-#ifdef SHRAY_DIAGNOSTICS
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
     {   // how much a triangle-parallel leaf stage could save: stages, and 64-wide rounds over all parked triangles
         unsigned int total = (state == LT_LEAF) ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
         for (int off = 32; off > 0; off >>= 1)
@@ -577,6 +597,113 @@ __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t,
     } while (wave_ballot(j < mine));
 }
 
+// Leaf cache (round 5).  The lanes of a wave that are parked TOGETHER mostly sit in the same few leaves: the rays of an 8x8
+// tile reach a leaf side by side.  Stages with more than 32 parked lanes, the plain loop's share of the throughput form:
+// ONE distinct leaf in 51 % of them, two in 31 %, three in 11 %, at most four in 96 % (1M-triangle scene: 15 / 28 / 25 %,
+// at most four in 84 %; profiles/r05/leaf_stage_histograms.txt) -- and those stages are 71 % of all triangle rounds.
+// The plain loop fetched every lane's triangle in every round: three strided fetches (16 + 16 + 4 bytes per lane) per
+// round on the CU's one vector memory pipeline, which charges an instruction by its width, not by what its lanes read
+// (DESIGN.md section 5).  Here a stage first names the distinct leaves among its parked lanes (a scalar loop: the first
+// parked lane's leaf, a ballot of the lanes in the same one, the next ...), and each distinct leaf -- 36 x count
+// consecutive bytes of packed_tris -- is fetched ONCE, as consecutive 16-byte chunks by the wave's first lanes, straight
+// into a slot of the wave's slab in LDS (global_load_lds_dwordx4: no registers, nothing waits until the slots are read).
+// Every parked lane then runs its triangles in order, as before, reading them from its leaf's slot: a round is five LDS
+// reads, no fetch.  The lanes of leaves beyond the slab's kCacheSlots fetch their own triangles, as before, in the same rounds.
+// (A leaf has at most kCacheTriangles triangles when the frame's leaf cap is that low -- the shader's is 10 -- else the
+// uncached loop runs.)
+#ifndef SHRAY_LEAF_CACHE
+#define SHRAY_LEAF_CACHE 0                // measured slower (profiles/EXPERIMENTS.md R5.1): built as a variant library only
+#endif
+#ifndef SHRAY_LEAF_CACHE_SLOTS
+#define SHRAY_LEAF_CACHE_SLOTS 3
+#endif
+#ifndef SHRAY_LEAF_CACHE_DEALT
+#define SHRAY_LEAF_CACHE_DEALT 1          // the dealt stage's workers read cached leaves too
+#endif
+constexpr int kCacheSlots = SHRAY_LEAF_CACHE_SLOTS;
+constexpr uint32_t kCacheTriangles = 10;                         // 90 words = 23 chunks of 16 bytes
+constexpr uint32_t kCacheSlotBytes = 400;                        // 368 used; 100 words: consecutive slots start 4 banks apart
+constexpr uint32_t kCacheBytes = (uint32_t)kCacheSlots * kCacheSlotBytes;
+constexpr uint32_t kIdsBytes = 64;                               // the wave's `ids` table in front of its slab
+typedef __attribute__((address_space(1))) const void cache_global_ptr;
+typedef __attribute__((address_space(3))) void cache_lds_ptr;
+
+// One pass of the cache's fill: the first kCacheSlots distinct leaves among the lanes in `todo` (parked, not yet served) are
+// fetched into the slots; `now` = the lanes they serve (taken out of `todo`), `at` = a served lane's slot as a byte offset
+// into the slab.  Nothing waits: the fetches are in flight when this returns (leaf_cache_wait).
+__device__ __forceinline__ void leaf_cache_fill(const SceneView &sc, const LaneTraversal &t, bool &todo, bool &now, uint32_t &at, char *cache)
+{
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const char *tris = reinterpret_cast<const char *>(sc.packed_tris);
+    unsigned long long left = wave_ballot(todo);
+    now = false;
+    at = 0;
+#pragma unroll
+    for (int n = 0; n < kCacheSlots; n++) {
+        if (left != 0ull) {             // (uniform)
+            const int lead = __builtin_ctzll(left);
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)t.leaf_first, lead);
+            const uint32_t count = parked_count((uint32_t)__builtin_amdgcn_readlane((int)t.leaf_count, lead), t.leaf_cap);
+            const bool same = todo && t.leaf_first == first;      // (one leaf, one record: the same count)
+            left &= ~wave_ballot(same);
+            if (same)
+                at = (uint32_t)n;   // (the slot's number: an inline constant; its byte offset below)
+            now = now || same;
+            todo = todo && !same;
+            // whatever lies behind the leaf's last word comes along (the array ends in a spare record, capi.hip) and is
+            // never read back
+            const uint32_t chunks = (count << 1) + ((count + 3u) >> 2);   // ceil(9 count / 4)
+            if (lane < chunks)
+                __builtin_amdgcn_global_load_lds((cache_global_ptr *)(tris + (size_t)(first * 36u) + (lane << 4)),
+                                                 (cache_lds_ptr *)(cache + (uint32_t)n * kCacheSlotBytes), 16, 0, 0);
+        }
+    }
+    at = __umul24(at, kCacheSlotBytes);
+}
+// The slots are read by other lanes than wrote them: the fetches have landed (their counter says so), and the compiler keeps
+// the reads behind this point.  (`pin`: any value the reads' addresses depend on.)
+__device__ __forceinline__ void leaf_cache_wait(uint32_t &pin) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin) : : "memory"); }
+
+// a triangle's nine words from a slot (five LDS reads), as the three words the tests unpack
+__device__ __forceinline__ void load_cached_triangle(const char *p, float4 &q0, float4 &q1, float4 &q2)
+{
+    const float *q = reinterpret_cast<const float *>(p);
+    float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7], a8 = q[8];
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
+    q0 = make_float4(a0, a1, a2, a3);
+    q1 = make_float4(a4, a5, a6, a7);
+    q2 = make_float4(a8, 0.0f, 0.0f, 0.0f);
+}
+
+// The sequential loop over a stage whose first kCacheSlots distinct leaves come through the cache: a lane whose leaf has a
+// slot reads its triangles from there, a lane whose leaf has none (a stage with more distinct leaves: the divergent waves,
+// the ones a lone frame waits for) fetches them itself as before -- in the same rounds.
+template <bool COUNT, bool BOUNDS>
+__device__ __forceinline__ void leaf_loop_cached(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc, char *cache SHRAY_DIAG_PARAM)
+{
+    bool todo = state == LT_LEAF, served;
+    uint32_t where;                         // the lane's next triangle: a byte offset into the slab (served) or into packed_tris
+    leaf_cache_fill(sc, t, todo, served, where, cache);
+    if (!served)
+        where = __umul24(t.leaf_first, 36u);
+    uint32_t mine = state == LT_LEAF ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
+    leaf_cache_wait(mine);
+    uint32_t j = 0;
+    do {
+        SHRAY_DIAG_COUNT(1);
+        if (j < mine) {
+            float4 q0, q1, q2;
+            if (served)
+                load_cached_triangle(cache + where, q0, q1, q2);
+            else
+                load_packed_triangle_at(sc, where, q0, q1, q2);
+            lane_test_triangle_loaded<COUNT, BOUNDS>(sc, t, t.leaf_first + j, rc, q0, q1, q2);
+        }
+        j++;
+        where += 36u;
+    } while (wave_ballot(j < mine));
+}
+
 // ... and its end: the parked lanes move on (fs:416-433)
 template <bool COUNT, int BLOCK, bool PAIR>
 __device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &t, int &state, uint32_t *stack, RayCounters &rc)
@@ -601,13 +728,17 @@ __device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &
         state = lane_advance<BLOCK>(t, stack, false, 0u);
 }
 
-template <bool COUNT, int BLOCK, bool PAIR = false>
+// CACHE: `ids` is followed by the wave's leaf cache (above)
+template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false>
 __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                           uint32_t *stack, RayCounters &rc SHRAY_DIAG_PARAM)
+                                           uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
 {
     if (!wave_ballot(state == LT_LEAF))
         return;
-    leaf_loop<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+    if (CACHE && t.leaf_cap <= kCacheTriangles)     // (uniform)
+        leaf_loop_cached<COUNT, !PAIR>(sc, t, state, rc, reinterpret_cast<char *>(ids) + kIdsBytes SHRAY_DIAG_ARG_FWD);
+    else
+        leaf_loop<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
 }
 
@@ -674,11 +805,23 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
 // a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
 // (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its
 // lane number)
-template <bool COUNT, bool BOUNDS>
+// CACHED: the stage's first kCacheSlots distinct leaves come through the wave's leaf cache (`ids` is followed by it); the
+// workers of a ray whose leaf got no slot fetch their triangles themselves, as before.
+template <bool COUNT, bool BOUNDS, bool CACHED>
 __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTraversal &t, int state, RayCounters &rc, uint8_t *ids,
                                              unsigned long long parked, int K, float &wd, float &wu, float &ww,
                                              uint32_t &won SHRAY_DIAG_PARAM)
 {
+    constexpr uint32_t kNoSlot = 0xffffffffu;
+    char *cache = reinterpret_cast<char *>(ids) + kIdsBytes;
+    uint32_t my_slot = kNoSlot;
+    const bool cached = CACHED && t.leaf_cap <= kCacheTriangles;   // (uniform; a larger leaf cap: every group fetches for itself)
+    if (cached) {
+        bool todo = state == LT_LEAF, now;
+        uint32_t at;
+        leaf_cache_fill(sc, t, todo, now, at, cache);
+        my_slot = now ? at : kNoSlot;
+    }
     const int log_g = K <= 4 ? 4 : (K <= 8 ? 3 : (K <= 16 ? 2 : 1));   // G = 16, 8, 4, 2
     const int G = 1 << log_g;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -692,25 +835,40 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
     const V3 P = mk(lane_pull(src, t.P.x), lane_pull(src, t.P.y), lane_pull(src, t.P.z));
     const V3 D = mk(lane_pull(src, t.D.x), lane_pull(src, t.D.y), lane_pull(src, t.D.z));
     const float r0 = lane_pull(src, t.leaf_r0), r1 = lane_pull(src, t.leaf_r1);
-    // worker i of a group walks triangles first + i, first + i + G, ... < end; the winner is kept as the triangle's index
+    // worker i of a group walks triangles i, i + G, ... < count of its ray's leaf; the winner is kept as that number
     const uint32_t first = (uint32_t)lane_pull(src, (int)t.leaf_first);
     // (every pull is a statement of its own, executed by all 64 lanes: ds_bpermute returns 0 for a source lane that
     // is masked off, so a pull must never sit inside a conditional expression)
     const uint32_t count = parked_count((uint32_t)lane_pull(src, (int)t.leaf_count), t.leaf_cap);
-    uint32_t end = worker ? first + count : 0u;
+    uint32_t end = worker ? count : 0u;
     asm volatile("" : "+v"(end));   // one comparison per round (see leaf_stage)
+    // where the worker's next triangle is: a byte offset into packed_tris -- or, if the ray's leaf has a slot in the cache,
+    // into the wave's slab (`served`)
+    uint32_t where = __umul24(first, 36u) + __umul24((uint32_t)sub, 36u);
+    bool served = false;
+    if (CACHED) {
+        const uint32_t slot = (uint32_t)lane_pull(src, (int)my_slot);
+        served = slot != kNoSlot;
+        if (served)
+            where = slot + __umul24((uint32_t)sub, 36u);
+        if (cached)
+            leaf_cache_wait(where);
+    }
     float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
     uint32_t best = 0xffffffffu;    // no candidate accepted
     bool unordered = false;         // accepted a candidate whose d is NaN (see above)
     uint32_t unordered_flag = 0u;   // the same, kept in a vector register by the tied form below
     SHRAY_DIAG_COUNT(6);
     // bottom-tested, like leaf_stage's loop: group 0's first worker always has a triangle
-    uint32_t tri = first + (uint32_t)sub;
+    uint32_t tri = (uint32_t)sub;
     do {
         SHRAY_DIAG_COUNT(1);
         if (tri < end) {
             float4 q0, q1, q2;
-            load_packed_triangle(sc, tri, q0, q1, q2);
+            if (CACHED && served)
+                load_cached_triangle(cache + where, q0, q1, q2);
+            else
+                load_packed_triangle_at(sc, where, q0, q1, q2);
             if (COUNT)
                 rc.triangle_tests++;
             float d, u, w;
@@ -735,6 +893,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
             }
         }
         tri += (uint32_t)G;
+        where += (uint32_t)G * 36u;
     } while (wave_ballot(tri < end));
     if (__builtin_expect(wave_ballot(unordered || unordered_flag != 0u) != 0ull, 0)) {
         asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
@@ -764,7 +923,8 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
 // One call site of the plain loop serves both the crowded stage (more than SHRAY_DEAL_MAX_PARKED lanes parked) and the
 // unordered fallback in the timed instances, and one end (leaf_finish) serves every path: each inlined copy is another
 // 150 instructions and another set of register copies where its results meet the other paths'.
-template <bool COUNT, int BLOCK, bool PAIR = false>
+// CACHE: `ids` is followed by the wave's leaf cache; the crowded stage's sequential loop reads its triangles from there
+template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false>
 __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
                                                  uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
 {
@@ -773,21 +933,59 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     if (!parked)
         return;
     const int K = __popcll(parked);
+#if defined(SHRAY_DIAGNOSTICS) && defined(SHRAY_DIAG_KHIST)
+    {
+        unsigned int most = (state == LT_LEAF) ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
+        for (int off = 32; off > 0; off >>= 1)
+            most = max(most, (unsigned int)__shfl_xor((int)most, off, 64));
+        const int bin = K == 1 ? 0 : (K == 2 ? 1 : (K <= 4 ? 2 : (K <= 8 ? 3 : (K <= 16 ? 4 : (K <= 32 ? 5 : 6)))));
+        const unsigned int g = K <= 4 ? 16u : (K <= 8 ? 8u : (K <= 16 ? 4u : (K <= 32 ? 2u : 1u)));
+        const unsigned long long rounds = (most + g - 1u) / g, chunks = (most * 9u + 3u) / 4u, staged = K > 32 ? 0ull : (chunks + g - 1u) / g;
+#if SHRAY_DIAG_KHIST == 1
+        diag_tally_ref[bin] += 1ull | (rounds << 24) | (staged << 44);
+        diag_tally_ref[7] += (unsigned long long)most | ((unsigned long long)K << 32);   // sums of the longest leaf and of K
+#else
+        // SHRAY_DIAG_KHIST == 2: the stages with more than SHRAY_DIAG_KHIST_FROM parked lanes by the number of DISTINCT leaves
+        // among them -- bins D = 1, 2, 3, 4, 5-8, 9-16, > 16 --, each word {stages; rounds}; [7] = sums of D and of K
+        if (K > SHRAY_DIAG_KHIST_FROM) {
+            unsigned long long left = parked;
+            int distinct = 0;
+            while (left) {
+                const int lead = __builtin_ctzll(left);
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)t.leaf_first, lead);
+                left &= ~wave_ballot(state == LT_LEAF && t.leaf_first == f);
+                distinct++;
+            }
+            const int dbin = distinct <= 4 ? distinct - 1 : (distinct <= 8 ? 4 : (distinct <= 16 ? 5 : 6));
+            diag_tally_ref[dbin] += 1ull | (rounds << 24);
+            diag_tally_ref[7] += (unsigned long long)distinct | ((unsigned long long)K << 32);
+        }
+        (void)bin;
+        (void)staged;
+#endif
+    }
+#endif
     float wd = 0.0f, wu = 0.0f, ww = 0.0f;
     uint32_t won = 0xffffffffu;
     bool plain = K > SHRAY_DEAL_MAX_PARKED, tallied = false;
     if (!plain) {
-        plain = dealt_search<COUNT, BOUNDS>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
+        plain = dealt_search<COUNT, BOUNDS, CACHE && SHRAY_LEAF_CACHE_DEALT != 0>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
         tallied = true;
     }
     if (plain) {
-        if (COUNT && !tallied)
+        if (CACHE && t.leaf_cap <= kCacheTriangles) {     // (uniform)
+            char *cache = reinterpret_cast<char *>(ids) + kIdsBytes;
+            if (COUNT && !tallied)
+                leaf_loop_cached<COUNT, BOUNDS>(sc, t, state, rc, cache SHRAY_DIAG_ARG_FWD);
+            else
+                leaf_loop_cached<false, BOUNDS>(sc, t, state, rc, cache SHRAY_DIAG_ARG_FWD);
+        } else if (COUNT && !tallied)
             leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
         else
             leaf_loop<false, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     } else if (state == LT_LEAF && won != 0xffffffffu) {
-        // the parked lane takes its group's winner
-        t.hit.which = (float)won;
+        // the parked lane takes its group's winner (its number in the leaf)
+        t.hit.which = (float)(t.leaf_first + won);
         t.hit.t = wd;
         t.hit.bu = wu;
         t.hit.bv = ww;

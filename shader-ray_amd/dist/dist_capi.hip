@@ -585,8 +585,16 @@ int shray_dist_copy_output(shray_dist *dist, int buffer_set, int count, void *d_
     if (assembled == 0)
         return SHRAY_OK;
     HIP_TRY(hipSetDevice(dist->device));
-    HIP_TRY(hipMemcpyAsync(d_dst, dist->sets[(size_t)buffer_set].output, (size_t)assembled * dist->r.width * dist->r.height * 16,
-                           hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    BufferSet &b = dist->sets[(size_t)buffer_set];
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // The copy reads the set's output: it follows the step that wrote it whichever stream that ran on, and the set's NEXT step
+    // -- on any stream -- must follow the copy (a lone rank renders straight into `output`, the others de-interleave into
+    // it): `finished` moves behind the copy, so shray_dist_step's wait covers it.
+    if (b.used)
+        HIP_TRY(hipStreamWaitEvent(stream, b.finished, 0));
+    HIP_TRY(hipMemcpyAsync(d_dst, b.output, (size_t)assembled * dist->r.width * dist->r.height * 16, hipMemcpyDeviceToDevice, stream));
+    if (b.used)
+        HIP_TRY(hipEventRecord(b.finished, stream));
     return SHRAY_OK;
 }
 

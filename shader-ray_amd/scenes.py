@@ -23,6 +23,7 @@ import numpy as np
 __all__ = [
     "lobed_sphere_mesh", "write_trisrc", "write_obj", "bunny_class_trisrc", "million_triangle_obj",
     "environment_constant", "environment_grid", "environment_hdr_sky",
+    "scene_file", "bunny_trisrc", "million_obj", "small_trisrc", "small_obj_no_normals",
 ]
 
 
@@ -200,3 +201,37 @@ def cached_path(name: str) -> str:
     root = os.environ.get("SHRAY_SCENE_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "shray_scenes"))
     os.makedirs(root, exist_ok=True)
     return os.path.join(root, name)
+
+
+def scene_file(name: str, maker) -> str:
+    """Generates `name` once per machine under the scene cache (maker(path) writes it) and returns its path."""
+    path = cached_path(name)
+    if not os.path.exists(path):
+        tmp = path + ".tmp%d" % os.getpid() + os.path.splitext(path)[1]
+        maker(tmp)
+        os.replace(tmp, path)
+    return path
+
+
+def bunny_trisrc() -> str:
+    """The benchmark mesh of BASELINE configs 1, 2, 3 and 5 (stand-in for bunny.trisrc) as a trisrc file."""
+    return scene_file("bunny_class_132x264.trisrc", bunny_class_trisrc)
+
+
+def million_obj() -> str:
+    """BASELINE config 4's 1M-triangle OBJ (no `vn` lines: the loader synthesizes the normals)."""
+    return scene_file("million_501x1000.obj", million_triangle_obj)
+
+
+def small_trisrc() -> str:
+    def make(path):
+        pos, tri = lobed_sphere_mesh(24, 48, bumpiness=0.22, ears=True)
+        write_trisrc(path, pos, tri)
+    return scene_file("small_lobed_24x48.trisrc", make)
+
+
+def small_obj_no_normals() -> str:
+    def make(path):
+        pos, tri = lobed_sphere_mesh(40, 64, bumpiness=0.15, ears=False, scale=3.0, center=(5.0, -2.0, 1.0))
+        write_obj(path, pos, tri)
+    return scene_file("small_sphere_40x64.obj", make)

@@ -211,6 +211,73 @@ def test_one_buffer_set_driven_from_two_streams(pkg, gpu):
     scene.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_a_late_copy_out_holds_the_next_step_back(pkg, gpu, ranks):
+    """the copy-out of a step's frames reads the set's output, which the set's NEXT step overwrites (a lone
+    rank renders straight into it, the others de-interleave into it) -- from another stream if the caller says so.  Made
+    deterministic: the copy-out's stream is held up for ~50 ms (a spin kernel) before the copy is enqueued, while the next
+    step runs on a free stream.  The copy must still deliver the frames of ITS step: shray_dist_copy_output leaves the
+    set's `finished` event behind the copy, and the next step waits for it."""
+    import torch
+    from shader_ray_amd import multigpu
+    W, H, frames, steps = 333, 200, 2, 4
+    env = pkg.scenes.environment_hdr_sky(128)
+    world = pkg.World(os.path.join(GOLDEN, "lobed_528.trisrc"))
+    desc = world.flatten()
+    view = world.default_view()
+    params = []
+    for s in range(steps):
+        row = []
+        for f in range(frames):
+            pkg.host.trackball_motion(view.object_rotation, 0.05, 0.02)
+            row.append(world.frame_params(W, H, view, material=(0, 6)[(s + f) % 2]))
+        params.append(row)
+    hub = multigpu.Hub(ranks)
+    got, errors = {}, []
+    lock = threading.Lock()
+    barrier = threading.Barrier(ranks)
+
+    def body(rank):
+        try:
+            torch.cuda.set_device(0)
+            scene = pkg.Scene(desc, env, device=0)
+            me = multigpu.Rank(scene, multigpu.make_config(rank, ranks, W, H, 1, frames, multigpu.ROTATE, multigpu.LOOPBACK, None, 32, 32,
+                                                           True, buffer_sets=1), hub)
+            step_streams = [torch.cuda.Stream(device=0) for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=0)
+            barrier.wait()
+            mine = {}
+            for s in range(steps):
+                me.step(params[s], 0, step_streams[s % 2].cuda_stream)
+                with torch.cuda.stream(copy_stream):
+                    torch.cuda._sleep(100_000_000)          # ~50 ms at the shader clock: the copy below starts late
+                for f, t in me.frames(0, frames, copy_stream.cuda_stream).items():
+                    mine[(s, f)] = t
+            torch.cuda.synchronize()
+            with lock:
+                got.update({k: t.cpu().numpy() for k, t in mine.items()})
+            barrier.wait()
+            me.close()
+            scene.close()
+        except Exception as exc:   # noqa: BLE001
+            errors.append((rank, repr(exc)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    hub.close()
+    assert not errors, errors
+    scene = pkg.Scene(desc, env, device=0)
+    assert len(got) == steps * frames
+    for (s, f), frame in got.items():
+        assert np.array_equal(frame, scene.render(params[s][f], W, H, 1)), (s, f)
+    scene.close()
+
+
 def test_bench_launches_its_own_ranks(gpu, tmp_path):
     """`python bench.py --gpus 2` with no launcher typed by hand: the parent makes no GPU call, starts
     torch.distributed.run as a child, relays rank 0's line.  On this one-GPU box both ranks share cuda:0 and the tile

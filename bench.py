@@ -51,6 +51,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-instructions / s
 PMC_FILE = os.path.join("profiles", "r04", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
 ISA_COSTS = os.path.join("profiles", "r04", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
+VMEM_MIX = os.path.join("profiles", "r05", "vmem_class_mix.json")  # distinct records per vector-memory instruction, measured (histogram builds)
 WARM_SECONDS = 0.15        # back-to-back frames before the first trial, beyond the W warm-up steps: the GPU's clock ramps
 
 
@@ -97,11 +98,44 @@ def algorithmic_ops(counters, costs):
             + k["c_env"] * c["env_lookups"] + k["c_pixel"] * c["samples"])
 
 
-def launch_ranks(n):
+def _kill_tree(pid):
+    """Ends process `pid`, its process group and every descendant (torch.distributed.run's workers): SIGTERM, five seconds, SIGKILL."""
+    import signal
+    victims = []
+    try:
+        import psutil
+        root = psutil.Process(pid)
+        victims = root.children(recursive=True) + [root]
+    except Exception:   # noqa: BLE001
+        pass
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(pid, sig)          # the child was started as the leader of its own process group
+        except (ProcessLookupError, PermissionError):
+            pass
+        for v in victims:
+            try:
+                v.send_signal(sig)
+            except Exception:   # noqa: BLE001
+                pass
+        deadline = time.time() + 5.0
+        while time.time() < deadline and any(v.is_running() for v in victims):
+            time.sleep(0.1)
+
+
+def timeout_line(n, budget, where):
+    return json.dumps({"error": "rank timeout", "n_gpus": n, "timeout_s": budget, "where": where, "value": None,
+                       "metric": "Mrays/s at 1920x1080 1spp (bunny.trisrc); 1/2/4/8-GPU scaling", "unit": "Mrays/s"})
+
+
+def launch_ranks(n, budget):
     """`python bench.py --gpus N` without a launcher: this process has made no GPU call (torch is not even imported); it
     starts one rank per GPU with torch.distributed.run as a CHILD process (never an exec), passes its own arguments on,
     relays the child's output (rank 0 prints the JSON line) and returns the child's exit code -- non-zero if any rank fails
-    (torch.distributed.run ends the other ranks and reports the failure)."""
+    (torch.distributed.run ends the other ranks and reports the failure).  The child gets `budget` seconds of wall clock
+    (--rank-timeout): a communicator that never comes up or an exchange that never ends must not hang the caller -- on expiry
+    the child's process group and all its descendants are killed, ONE line {"error": "rank timeout", ...} goes to stdout and
+    the exit code is 124."""
     import socket
     import subprocess
     with socket.socket() as sock:
@@ -109,8 +143,43 @@ def launch_ranks(n):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd))
-    return subprocess.call(cmd)
+    log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd), f"(budget {budget:.0f} s)")
+    # the ranks' own watchdogs (arm_watchdog) fire first and say where they were; this budget is the backstop behind them
+    child = subprocess.Popen(cmd, start_new_session=True)
+    try:
+        return child.wait(timeout=budget + float(os.environ.get("SHRAY_BENCH_PARENT_SLACK", "120")) if budget > 0 else None)   # (slack: a fresh box's first `import torch`)
+    except subprocess.TimeoutExpired:
+        log(f"bench.py: the ranks did not finish within {budget:.0f} s: killing them")
+        _kill_tree(child.pid)
+        print(timeout_line(n, budget, "parent: the child process group was killed"), flush=True)
+        return 124
+
+
+_watchdog = {"stage": "start-up", "timer": None}
+
+
+def arm_watchdog(rank, n, budget):
+    """Inside a rank (also when a launcher other than launch_ranks started it, as the driver's torch.distributed.run does): a
+    timer thread that, `budget` seconds after start-up, reports the stage the rank was in on stderr, has rank 0 print the
+    one-line {"error": "rank timeout"} and leaves with os._exit(124) -- a hung ncclCommInitRank or grouped exchange blocks
+    the main thread inside a C call, which no Python exception reaches."""
+    import threading
+
+    def fire():
+        log(f"bench.py: rank {rank} of {n} is still in '{_watchdog['stage']}' after {budget:.0f} s: giving up")
+        if rank == 0:
+            print(timeout_line(n, budget, f"rank 0 was in: {_watchdog['stage']}"), flush=True)
+        os._exit(124)
+
+    if budget > 0:
+        t = threading.Timer(budget, fire)
+        t.daemon = True
+        t.start()
+        _watchdog["timer"] = t
+
+
+def stage(name):
+    _watchdog["stage"] = name
 
 
 def main():
@@ -137,11 +206,14 @@ def main():
                          "root0 = every frame on rank 0 (gather)")
     ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: exchange RGBA instead of RGB (alpha is the constant 1)")
     ap.add_argument("--same-view", action="store_true", help="every frame renders the first view of the orbit (round 2's loop)")
+    ap.add_argument("--rank-timeout", type=float, default=300.0,
+                    help="N > 1: wall-clock budget in seconds for the whole multi-rank run; on expiry the ranks are killed, ONE line "
+                         '{"error": "rank timeout", ...} is printed and the exit code is 124 (0 = no budget)')
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args.gpus, args.rank_timeout))
 
     import torch
     import torch.distributed as dist
@@ -159,6 +231,16 @@ def main():
     # RCCL (which refuses two ranks on one GPU) for the library's CALLBACK transport over gloo, staging the tile buffers
     # through host memory.  Only the control flow is rehearsed that way, never a reported number.
     one_gpu = os.environ.get("SHRAY_BENCH_ONE_GPU") == "1"
+    if distributed and os.environ.get("SHRAY_BENCH_NO_RANK_WATCHDOG") != "1":
+        arm_watchdog(rank, world_size, args.rank_timeout)
+    # SHRAY_BENCH_STALL_RANK=k|all (a test knob): that rank stops for good -- at SHRAY_BENCH_STALL_AT=start (before its first GPU
+    # call) or =communicator (the default: it never arrives at the communicators, what a hung ncclCommInitRank looks like to
+    # the others); the run must end with the one-line timeout record (tests/test_multigpu_cpu.py, tests/test_gpu_dist.py)
+    stalled = os.environ.get("SHRAY_BENCH_STALL_RANK") in (str(rank), "all")
+    if stalled and os.environ.get("SHRAY_BENCH_STALL_AT") == "start":
+        stage("stalled on purpose (SHRAY_BENCH_STALL_RANK, at start)")
+        time.sleep(10 ** 6)
+    stage("process group (gloo rendezvous)")
     transport_name = os.environ.get("SHRAY_BENCH_TRANSPORT", "rccl")
     if one_gpu:
         local_rank = 0
@@ -179,6 +261,7 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
+    stage("scene load")
     pkg = load_package()
     # rank 0 generates the scene file once; the others wait for it
     if rank == 0:
@@ -258,7 +341,11 @@ def main():
                 return None, f"ranks {[k for k, f in enumerate(failures) if f]}: " + next(f for f in failures if f)
             return made, None
 
+        if stalled:
+            stage("stalled on purpose (SHRAY_BENCH_STALL_RANK, in front of the communicators)")
+            time.sleep(10 ** 6)
         for name in [args.root_mode] + [m for m in mode_ids if m != args.root_mode]:
+            stage(f"communicator for root mode {name} (ncclCommInitRank / callback transport)")
             if transport_name == "gloo":
                 ranks[name], _ = make_rank(mode_ids[name], multigpu.CALLBACK)
                 continue
@@ -390,6 +477,7 @@ def main():
                 differing += 0 if torch.equal(frame_outs[0][k * HEIGHT * WIDTH * 4:(k + 1) * HEIGHT * WIDTH * 4], whole) else 1
         return compared, differing
 
+    stage("warm-up and timed trials (shray_dist_step: render, pack, grouped exchange, de-interleave)" if distributed else "timed trials")
     trial_s, warm_ms, warm_frames = timed_trials()
     elapsed = sorted(trial_s)[len(trial_s) // 2]
     alt = None
@@ -407,7 +495,9 @@ def main():
                    "what": ("every frame gathered on rank 0 (north_star's gather; link-bound at 1 spp: DESIGN.md section 6)"
                             if name == "root0" else "frame f of a step assembled on rank f % N (all-to-all over every xGMI link)")}
         active["rank"] = me
+    stage("frame verification")
     frames_compared, frames_differing = verify_frames()
+    stage("counters, roofline and the report")
 
     result = None
     frames_per_s = args.steps / elapsed
@@ -463,29 +553,52 @@ def main():
             costs = json.load(open(os.path.join(ROOT, ISA_COSTS)))
         except Exception as exc:   # noqa: BLE001
             costs_note = f"{ISA_COSTS} unreadable: {exc}"
-        roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Gwaveinst/s", "frac": None,
-                "traffic": None,
-                "why": "the scene + environment working set (32 MB) is cache-resident: the kernel is co-limited by VALU issue (four "
-                       "SIMDs per CU) and by the CU's one vector memory pipeline, not by HBM (DESIGN.md sections 4, 5); both are "
-                       "reported (valu_issue, vector_memory), the headline pair is the busier one; HBM use is hbm_frac"}
+        gpus = world_size if distributed else 1
+        # ---- the roofline object (definition frozen in round 5; DESIGN.md section 5 derives every number) ----------------
+        # Three resources, each as achieved / peak with achieved = a COUNT per frame x this run's frames per second:
+        #   hbm    bytes: SURVEY 8(d)'s cache-less count of the reference's fetches (algorithmic) and the bytes the HBM
+        #          counters saw (measured); peak 8000 GB/s.  The algorithmic rate exceeds the peak (the working set is
+        #          cache-resident), so north_star's ">= 60 % of the HBM roofline" has no meaning here; frac_measured is
+        #          what the path really asks of HBM
+        #   vmem   vector-memory wave-instructions (SQ_INSTS_VMEM_RD) against the rate the CU's vector memory pipeline
+        #          sustains for the kernel's MEASURED mix of distinct records per instruction (probed in this run)
+        #   valu   vector-ALU wave-instructions (SQ_INSTS_VALU) against 256 CUs x 4 SIMDs x 2.4 GHz / 2
+        # Top level: bound / achieved / peak / unit / frac are those of the resource with the largest frac; traffic = the
+        # measured HBM bytes per launch.  Counts per frame come from committed rocprofv3 --pmc passes of THIS command on THIS
+        # device code (instruction and byte counts of a deterministic kernel; keyed by the code objects' hash); the frame
+        # rate, the launch durations (HIP events) and the vmem peak are measured in this run.  Busy counters of the
+        # profiled run are reported under busy_profiled, named *_busy, and enter no frac.
+        algo_gbs = algo_bytes * frames_per_s / 1e9
+        roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "definition": "r05: frac = max over {hbm.frac_measured, vmem.frac, valu.frac}, each = count per frame x frames/s of this run / peak",
+                "hbm": {"algorithmic_bytes_per_frame": algo_bytes, "algorithmic_bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
+                        "algorithmic_gbs": round(algo_gbs, 2), "peak_gbs": HBM_PEAK_GBS * gpus,
+                        "algorithmic_over_peak": round(algo_gbs / (HBM_PEAK_GBS * gpus), 4),
+                        "measured_bytes_per_frame": None, "measured_gbs": None, "frac_measured": None,
+                        "north_star_60_percent": "not applicable: the algorithmic bytes (32 Nv + 8 Lv + 36 Tt + 18 H + 48 E + 16 P, SURVEY 8(d)) are "
+                                                 "served by the vector L1 / L2 (scene + environment = 32 MB working set), so their rate exceeds "
+                                                 "the HBM peak (algorithmic_over_peak > 1) while HBM itself carries frac_measured of its peak"},
+                "vmem": {"insts_per_frame": None, "insts_per_s_g": None, "peak_g": None, "frac": None},
+                "valu": {"insts_per_frame": None, "insts_per_s_g": None, "peak_g": VALU_PEAK_GINST, "frac": None, "necessary_frac": None,
+                         "lane_util": None}}
         if costs:
             # wave-instructions a frame would take if every lane of every instruction did arithmetic the shader asks for
             ops = algorithmic_ops(counters_timed, costs) / 64.0
-            gops = ops * frames_per_s / 1e9 / (world_size if distributed else 1)
-            roof["algorithmic_ops"] = {
-                "wave_insts_per_frame": round(ops, 1), "gwaveinst_per_s_per_gpu": round(gops, 2),
-                "costs": {k: v for k, v in costs.items() if k.startswith("c_")}, "costs_source": costs_note,
+            gops = ops * frames_per_s / 1e9 / gpus
+            roof["valu"]["necessary_frac"] = round(gops / VALU_PEAK_GINST, 5)
+            roof["valu"]["necessary"] = {
+                "wave_insts_per_frame": round(ops, 1), "costs": {k: v for k, v in costs.items() if k.startswith("c_")}, "costs_source": costs_note,
                 "formula": "(c_node Nv + c_tri_distance Tt + (c_tri_barycentric + c_shade) H + c_setup Tr + c_env E + c_pixel S) / 64 "
                            "from counters_timed; tests that reach the barycentric part are counted as H (a lower bound)"}
-            roof["necessary_frac"] = round(gops / VALU_PEAK_GINST, 5)
         if not distributed:
             # per-launch kernel time: HIP events recorded around every EVENT_STRIDE-th launch of every trial, on the stream that
             # launch went to.  With frames_in_flight > 1 several launches share the GPU, so each lasts longer than it
-            # would alone while together they finish sooner: rates below use WALL time, not per-launch time.
+            # would alone while together they finish sooner: rates use WALL time, not per-launch time.
             kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
             avg_ms = sum(kernel_ms) / len(kernel_ms)   # per LAUNCH (a launch carries `batch` frames)
-            # hardware counters of the dominant kernel come from a committed rocprofv3 --pmc run of THIS command
-            # (they cannot be read from inside the process); used only if they were taken on this workload
+            roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
+                         "concurrent_launches": lanes, "frames_per_launch": batch,
+                         "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed by HIP events on their own streams (every {EVENT_STRIDE}th)"})
             pmc, pmc_note = None, "no counter file"
             try:
                 sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -496,113 +609,91 @@ def main():
                         (WIDTH, HEIGHT, SPP, args.kernel, batch, 1 if args.same_view else ORBIT) and cand["valu_insts_per_launch"] \
                         and args.material == 0:
                     pmc = cand
-                    pmc_note = PMC_FILE + (" (same kernel sources as this build)" if cand["build_hash"] == kernel_source_hash()
-                                           else " (STALE: measured on different kernel sources than this build)")
+                    pmc_note = PMC_FILE + (" (same device code as this build)" if cand["build_hash"] == kernel_source_hash()
+                                           else " (STALE: measured on other device code than this build's)")
                 else:
                     pmc_note = PMC_FILE + " is for another workload"
             except Exception as exc:   # noqa: BLE001
                 pmc_note = f"{PMC_FILE} unreadable: {exc}"
-            roof.update({"traffic_source": pmc_note, "counter_source": pmc_note, "lane_util": None, "hbm_frac": None})
-            if pmc:
-                fpl = pmc["workload"].get("frames_per_launch", 1)   # the profiled launches carried this many frames each
-                ginst = pmc["valu_insts_per_launch"] / fpl * frames_per_s / 1e9
-                roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 5),
-                             "lane_util": round(pmc["lane_util"], 4) if pmc.get("lane_util") else None,
-                             "useful_frac": round(ginst / VALU_PEAK_GINST * pmc["lane_util"], 5) if pmc.get("lane_util") else None,
-                             "valu_insts_per_frame": pmc["valu_insts_per_launch"] / fpl,
-                             "profiled_kernel_us": pmc.get("kernel_trace_avg_us")})
-                if costs:
-                    roof["necessary_of_issued"] = round(roof["algorithmic_ops"]["wave_insts_per_frame"] / (pmc["valu_insts_per_launch"] / fpl), 4)
-                if pmc.get("hbm_bytes_per_launch"):
-                    hbm_gbs = pmc["hbm_bytes_per_launch"] / fpl * frames_per_s / 1e9
-                    roof.update({"traffic": pmc["hbm_bytes_per_launch"], "traffic_frames": fpl, "hbm_gbs": round(hbm_gbs, 2),
-                                 "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 5)})
+            roof["counter_source"] = pmc_note
             # The vector memory pipeline: one per CU (texture addresser + vector L1 + texture data), shared by the CU's four
-            # SIMDs.  Its peak is measured HERE, on this GPU, by shray_probe_vector_cache: wave-instructions of 16 bytes per
-            # lane per second when nothing else is done and every lane reads the same record (the pipeline's floor of ~14
-            # cycles per instruction: profiles/r04/vector_cache_probe.json; lanes that read different cache lines cost more);
-            # achieved = the kernel's vector-memory instructions (SQ_INSTS_VMEM_RD of the profiled run) x frames per second
+            # SIMDs.  What it sustains depends on how many distinct records the lanes of an instruction read
+            # (shray_probe_vector_cache: ~12.5 CU-cycles with every lane at one record, ~24 with two to four records spread over
+            # the lanes, ~44 with eight, ~54 with every lane elsewhere).  The kernel's instructions are priced by the mix of
+            # those classes that was MEASURED on this workload (profiles/r05/vmem_class_mix.json: histograms of distinct nodes
+            # per wave-visit and of distinct leaves per leaf stage); each class's cost is probed here, in this run.
             import ctypes as C
             probe_waves, probe_visits = 256 * 4 * 7 * 8, 512
-            sec, nbytes = C.c_double(), C.c_uint64()
-            pkg._native.check(pkg._native.load_hip().shray_probe_vector_cache(32768, 1, probe_visits, probe_waves, 0xffffffffffffffff, 32,
-                                                                              C.byref(sec), C.byref(nbytes)))
-            vmem_peak = probe_waves * probe_visits * 2 / sec.value / 1e9          # G wave-instructions / s
-            vmem = {"peak": round(vmem_peak, 2), "unit": "Gwaveinst/s (16 bytes per lane)",
-                    "peak_source": "shray_probe_vector_cache in this run: every lane of a wave-instruction at one 32-byte record of a "
-                                   f"1 MB table, {probe_waves} one-wave workgroups x {probe_visits} visits x 2 loads in {sec.value * 1e3:.3f} ms",
-                    "achieved": None, "frac": None}
-            if pmc and pmc.get("vmem_insts_per_launch"):
-                fpl = pmc["workload"].get("frames_per_launch", 1)
-                gv = pmc["vmem_insts_per_launch"] / fpl * frames_per_s / 1e9
-                vmem.update({"achieved": round(gv, 2), "frac": round(gv / vmem_peak, 5), "vmem_insts_per_frame": pmc["vmem_insts_per_launch"] / fpl,
-                             "scalar_mem_insts_per_frame": (pmc.get("smem_insts_per_launch") or 0) / fpl,
-                             "ta_busy_frac": round(pmc["ta_busy_frac"], 4) if pmc.get("ta_busy_frac") else None,
-                             "td_busy_frac": round(pmc["td_busy_frac"], 4) if pmc.get("td_busy_frac") else None,
-                             "note": "frac prices every instruction at the floor; ta_busy_frac / td_busy_frac (TA_BUSY_avr, TD_BUSY_avr over "
-                                     "GRBM_GUI_ACTIVE / 8 of the profiled run) are how busy the pipeline was with what the lanes really read"})
-                roof["wait_frac"] = round(pmc["wait_frac"], 4) if pmc.get("wait_frac") else None
-            roof["vector_memory"] = vmem
-            roof["valu_issue"] = {"achieved": roof.get("achieved"), "peak": VALU_PEAK_GINST, "frac": roof.get("frac"), "unit": "Gwaveinst/s",
-                                  "busy_frac_profiled": round(pmc["valu_busy_frac_profiled"], 4) if pmc and pmc.get("valu_busy_frac_profiled") else None}
-            # `frac` prices every vector instruction at the peak's 2 cycles.  Only f32 add / sub / mul, 32-bit integer add and
-            # logic, register moves and VCC selects issue at that rate; fma, min / max, compares, other selects and anything
-            # with a scalar-register operand take 4, transcendentals 8 (profiles/r04/valu_costs_probe.txt).  From the mix the
-            # hardware counts (one more --pmc pass of the same command): the VALU's busy fraction lies between "only what is
-            # counted as fma / transcendental is slow" and "only what is counted as f32 add / mul is fast"
-            mix = pmc.get("valu_mix_per_launch") if pmc else None
-            if mix and pmc.get("valu_insts_per_launch") and roof.get("frac"):
-                total = pmc["valu_insts_per_launch"]
-                fast_sure = mix.get("add_f32", 0.0) + mix.get("mul_f32", 0.0)
-                fma, trans = mix.get("fma_f32", 0.0), mix.get("trans_f32", 0.0)
-                lo = (2.0 * (total - fma - trans) + 4.0 * fma + 8.0 * trans) / (2.0 * total)
-                hi = (2.0 * fast_sure + 8.0 * trans + 4.0 * (total - fast_sure - trans)) / (2.0 * total)
-                roof["valu_issue"].update({
-                    "frac_class_weighted": [round(roof["frac"] * lo, 4), round(roof["frac"] * hi, 4)],
-                    "mix_of_vector_instructions": {k: round(v / total, 4) for k, v in mix.items()},
-                    "frac_class_weighted_is": "frac x (cycles per instruction by class / 2): lower bound with only the counted fma and "
-                                              "transcendental instructions at 4 and 8 cycles, upper bound with only the counted f32 add / mul at 2"})
-            # The headline pair names the busier pipe.  Compared in ONE run, the profiled one (rocprofv3 runs a launch at a time
-            # while it counts: there a four-frame launch has the GPU to itself and every pipe is less busy than in the timed
-            # loop, whose launches overlap): VALU = 2 cycles x SQ_INSTS_VALU / (1024 SIMDs x the kernel's cycles), the vector
-            # memory pipeline = the busier of its two stages (texture addresser, texture data)
-            if pmc and pmc.get("valu_busy_frac_profiled") and (pmc.get("ta_busy_frac") or pmc.get("td_busy_frac")):
-                stage, busy = max((("texture addresser", pmc.get("ta_busy_frac") or 0.0), ("texture data", pmc.get("td_busy_frac") or 0.0)),
-                                  key=lambda kv: kv[1])
-                if busy > pmc["valu_busy_frac_profiled"]:
-                    roof.update({"bound": "vector_memory_pipeline", "frac": round(busy, 5), "peak": round(vmem_peak, 2),
-                                 "achieved": round(busy * vmem_peak, 2), "unit": "Gwaveinst/s (16 bytes per lane)",
-                                 "frac_is": f"the {stage} stage's busy fraction in the profiled run (VALU in the same run: "
-                                            f"{pmc['valu_busy_frac_profiled']:.3f}); achieved = frac x the peak measured in this run; "
-                                            "the timed loop's VALU fraction is valu_issue.frac"})
-            # The fractions above are of the PROFILED run, where rocprofv3 runs one launch at a time (a four-frame launch alone:
-            # serialized_launch_ms).  The timed loop overlaps launches and finishes a frame sooner; the work a frame hands each
-            # pipe is the same, so the pipe's busy fraction in the timed loop is its busy cycles per frame over the timed
-            # loop's cycles per frame (at the clock the profiled launches ran at): an estimate, reported beside the measurement
-            if pmc and pmc.get("serialized_launch_ms") and pmc.get("serialized_clock_ghz"):
-                fpl = pmc["workload"].get("frames_per_launch", 1)
-                # (the launch's own cycles, GRBM_GUI_ACTIVE / 8 -- what the profiled fractions are fractions of --, at that clock)
-                serial_ms = pmc["kernel_cycles_profiled"] / pmc["serialized_clock_ghz"] / 1e6 / fpl
-                scale = serial_ms / (elapsed / args.steps * 1e3)
-                est = {"serialized_ms_per_frame": round(serial_ms, 5), "clock_ghz": round(pmc["serialized_clock_ghz"], 3),
-                       "is": "profiled busy fraction x (profiled time per frame / timed time per frame): same work per frame, less time"}
-                for key, name in (("td_busy_frac", "texture_data_busy"), ("ta_busy_frac", "texture_addresser_busy")):
-                    if pmc.get(key):
-                        est[name] = round(pmc[key] * scale, 4)
-                if roof["valu_issue"].get("frac_class_weighted"):
-                    est["valu_busy_class_weighted"] = roof["valu_issue"]["frac_class_weighted"]
-                roof["timed_loop_estimate"] = est
-            roof.update({"kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
-                         "concurrent_launches": lanes, "frames_per_launch": batch,
-                         "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed (every {EVENT_STRIDE}th)"})
+            hip = pkg._native.load_hip()
+
+            def probe(spread, nbytes_lane):
+                sec, nb = C.c_double(), C.c_uint64()
+                pkg._native.check(hip.shray_probe_vector_cache(32768, spread, probe_visits, probe_waves, 0xffffffffffffffff, nbytes_lane,
+                                                               C.byref(sec), C.byref(nb)))
+                return sec.value / (probe_waves * probe_visits * (2 if nbytes_lane == 32 else 1))   # seconds per wave-instruction, chip-wide
+
+            vm = roof["vmem"]
+            try:
+                mix = json.load(open(os.path.join(ROOT, VMEM_MIX)))
+                per_inst, classes = 0.0, {}
+                for kind in mix["kinds"]:
+                    for records, share in kind["records_per_instruction"].items():
+                        t = probe(int(records), kind["probe_bytes_per_lane"])
+                        classes[f"{kind['name']}:{records}"] = {"share": round(kind["share_of_insts"] * share, 4),
+                                                                 "cu_cycles_per_inst": round(t * 256 * 2.4e9, 2)}
+                        per_inst += kind["share_of_insts"] * share * t
+                floor = probe(1, 32)
+                vm.update({"peak_g": round(1.0 / per_inst / 1e9, 2), "peak_at_one_record_g": round(1.0 / floor / 1e9, 2), "classes": classes,
+                           "mix_source": VMEM_MIX,
+                           "peak_is": "1 / sum over classes (share x seconds per wave-instruction of that class), the classes' costs probed in this "
+                                      "run (shray_probe_vector_cache, pseudo-random lanes per record, 1 MB table); peak_at_one_record is the "
+                                      "pipeline's floor (every lane at one record), the peak rounds 1-4 priced against"})
+            except Exception as exc:   # noqa: BLE001
+                vm["mix_source"] = f"{VMEM_MIX} unusable: {exc}"
+            if pmc:
+                fpl = pmc["workload"].get("frames_per_launch", 1)   # the profiled launches carried this many frames each
+                vi = pmc["valu_insts_per_launch"] / fpl
+                roof["valu"].update({"insts_per_frame": vi, "insts_per_s_g": round(vi * frames_per_s / 1e9, 2),
+                                     "frac": round(vi * frames_per_s / 1e9 / VALU_PEAK_GINST, 5),
+                                     "lane_util": round(pmc["lane_util"], 4) if pmc.get("lane_util") else None})
+                if costs:
+                    roof["valu"]["necessary_of_issued"] = round(roof["valu"]["necessary"]["wave_insts_per_frame"] / vi, 4)
+                mixv = pmc.get("valu_mix_per_launch")
+                if mixv:
+                    roof["valu"]["mix"] = {k: round(v / pmc["valu_insts_per_launch"], 4) for k, v in mixv.items()}
+                if pmc.get("vmem_insts_per_launch"):
+                    mi = pmc["vmem_insts_per_launch"] / fpl
+                    vm.update({"insts_per_frame": mi, "insts_per_s_g": round(mi * frames_per_s / 1e9, 3),
+                               "scalar_mem_insts_per_frame": (pmc.get("smem_insts_per_launch") or 0) / fpl})
+                    if vm.get("peak_g"):
+                        vm["frac"] = round(mi * frames_per_s / 1e9 / vm["peak_g"], 5)
+                        vm["frac_at_one_record_peak"] = round(mi * frames_per_s / 1e9 / vm["peak_at_one_record_g"], 5)
+                if pmc.get("hbm_bytes_per_launch"):
+                    hb = pmc["hbm_bytes_per_launch"] / fpl
+                    roof["hbm"].update({"measured_bytes_per_frame": hb, "measured_gbs": round(hb * frames_per_s / 1e9, 2),
+                                        "frac_measured": round(hb * frames_per_s / 1e9 / HBM_PEAK_GBS, 5),
+                                        "measured_over_algorithmic": round(hb / algo_bytes, 5),
+                                        "measured_is": "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch / frames per launch, MI355X_MICROARCH.md's gfx950 correction"})
+                    roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                    roof["traffic_frames"] = fpl
+                # busy counters of the PROFILED run (rocprofv3 runs one launch at a time while it counts: a four-frame launch alone on
+                # the GPU); none of them is a fraction of a peak rate
+                roof["busy_profiled"] = {
+                    "texture_data_busy": round(pmc["td_busy_frac"], 4) if pmc.get("td_busy_frac") else None,
+                    "texture_addresser_busy": round(pmc["ta_busy_frac"], 4) if pmc.get("ta_busy_frac") else None,
+                    "valu_busy_at_2_cycles": round(pmc["valu_busy_frac_profiled"], 4) if pmc.get("valu_busy_frac_profiled") else None,
+                    "wave_cycles_waiting": round(pmc["wait_frac"], 4) if pmc.get("wait_frac") else None,
+                    "serialized_launch_ms": pmc.get("serialized_launch_ms"), "profiled_kernel_us": pmc.get("kernel_trace_avg_us"),
+                    "of": "TD_TD_BUSY_sum / 256 CUs, TA_TA_BUSY_sum / 256, 2 x SQ_INSTS_VALU / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+            pairs = [("hbm", roof["hbm"]["frac_measured"], roof["hbm"]["measured_gbs"], HBM_PEAK_GBS, "GB/s"),
+                     ("vmem", vm.get("frac"), vm.get("insts_per_s_g"), vm.get("peak_g"), "Gwaveinst/s (vector memory)"),
+                     ("valu", roof["valu"]["frac"], roof["valu"]["insts_per_s_g"], VALU_PEAK_GINST, "Gwaveinst/s (vector ALU)")]
+            pairs = [q for q in pairs if q[1] is not None]
+            if pairs:
+                name, frac, achieved, peak, unit = max(pairs, key=lambda q: q[1])
+                roof.update({"bound": name, "frac": frac, "achieved": achieved, "peak": peak, "unit": unit})
         else:
-            roof["traffic_source"] = "not collected for N > 1 (see the N = 1 line)"
-        algo_gbs = algo_bytes * frames_per_s / 1e9
-        roof["algorithmic_cacheless"] = {
-            "bytes_per_frame": algo_bytes, "bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
-            "gbs": round(algo_gbs, 2),
-            "note": "SURVEY 8(d)'s cache-less count of the REFERENCE's fetches x frames / wall time (all GPUs together); these bytes are "
-                    "served by L1/L2, not by HBM: not a bound (it exceeds the 8000 GB/s HBM peak), no fraction is formed from it"}
+            roof["counter_source"] = "not collected for N > 1 (see the N = 1 line)"
         result["roofline"] = roof
 
     if not distributed:
@@ -659,10 +750,13 @@ def main():
             result["alt_root_mode"] = alt
         print(json.dumps(result), flush=True)
     if distributed:
+        stage("shutdown")
         dist.barrier()
         for r in ranks.values():
             r.close()
         dist.destroy_process_group()
+    if _watchdog["timer"] is not None:
+        _watchdog["timer"].cancel()
     if frames_differing:
         raise SystemExit(f"{frames_differing} of {frames_compared} verified frames differ from the single-GPU render")
 

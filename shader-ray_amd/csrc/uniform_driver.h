@@ -19,6 +19,11 @@
 
 #include "trace_common.h"
 
+// 1: the lane's pixel is located again wherever it is needed instead of carried across the traversals (A/B builds: 0)
+#ifndef SHRAY_RECOMPUTE_PIXEL
+#define SHRAY_RECOMPUTE_PIXEL 1
+#endif
+
 namespace shray {
 
 // shadow rays stop at their first hit (stack_traversal.h: closest<COUNT, ANY_HIT>); 0 = walk them to the end
@@ -58,44 +63,69 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c_begin = __builtin_amdgcn_s_memtime();   // shader cycles: in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
-    int px, py;
-    size_t out_index;
-    bool store, inside;
-    uint32_t cost_patch = 0xffffffffu, cost_begin = 0;   // ORDERED: the patch this wave reports its running time for
-    // lanes per pixel (multi-sample frames in one-wave workgroups only): G = gx * gy, this lane runs samples
-    // sub, sub + G, ... of its pixel; base_lane = the pixel's lane with sub == 0
+    // Which pixel (and which of its samples) this lane renders.  Evaluated where it is needed -- in front of a round of samples
+    // for the primary ray, behind the last traversal for the store -- instead of once at the top: px, py, the output index and the
+    // lane's place in its pixel's block of sample lanes are a dozen instructions of integer arithmetic on the workgroup's index
+    // and the lane's number, and carried across the traversals they are six vector registers the traversal spills (round 5).
+    // The asm statements make each evaluation's inputs opaque, so that the compiler does not keep the first one's results.
     const bool sample_lanes = !ONE_SAMPLE && (!COUNT || TIMED_FORM) && Traversal::block_size == 64;
     const unsigned int log_gx = sample_lanes ? fr.sample_log_x : 0u, log_gy = sample_lanes ? fr.sample_log_y : 0u;
     const unsigned int G = 1u << (log_gx + log_gy);
-    unsigned int sub = 0, base_lane = threadIdx.x & 63u;
-    // a 256-thread workgroup is a 16x16 patch (four 8x8 wave tiles); a 64-thread workgroup is one of those tiles
+    struct LanePixel {
+        int px, py;
+        size_t out_index;
+        bool store, inside;
+        unsigned int sub, base_lane;   // lanes per pixel G = gx * gy: this lane runs samples sub, sub + G, ... of its pixel;
+                                       // base_lane = the pixel's lane with sub == 0
+        uint32_t patch;
+    };
+    auto locate = [&](bool again) -> LanePixel {
+        LanePixel lp;
+        lp.sub = 0;
+        lp.patch = 0;
+        unsigned int b = block_index;
+        // a 256-thread workgroup is a 16x16 patch (four 8x8 wave tiles); a 64-thread workgroup is one of those tiles
+        if (Traversal::block_size == 64) {
+            // (one-wave workgroups: the lane's number is threadIdx.x; recomputed, it does not keep v0 alive)
+            unsigned int lane = (again && SHRAY_RECOMPUTE_PIXEL) ? __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : threadIdx.x;
+            if (again && SHRAY_RECOMPUTE_PIXEL) {
+                asm volatile("" : "+s"(b));
+                asm volatile("" : "+v"(lane));
+            }
+            lp.base_lane = lane;
+            // workgroups go to the eight XCDs round robin: keep the waves of a patch (four, or 4 G with sample lanes) on one
+            // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
+            // waves leave at once (the caller's test of `slot`).
+            const unsigned int log_waves = 2u + log_gx + log_gy;
+            const unsigned int k = b >> 3, slot = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
+            // heaviest patches first (capi.hip: DispatchOrder): which patch this slot of the launch renders
+            lp.patch = slot;
+            if (ORDERED)
+                lp.patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
+            // the patch as (16 gx) x (16 gy) lane positions, cut into 8x8 wave tiles: position (vx, vy) is sample
+            // (vy % gy) * gx + vx % gx of pixel (vx / gx, vy / gy)
+            const unsigned int tiles_across = 2u << log_gx;
+            const unsigned int vx = (wave & (tiles_across - 1u)) * 8u + (lane & 7u), vy = (wave >> (1u + log_gx)) * 8u + (lane >> 3);
+            const unsigned int sx = vx & ((1u << log_gx) - 1u), sy = vy & ((1u << log_gy) - 1u);
+            lp.sub = (sy << log_gx) | sx;
+            lp.base_lane = lane - (sy * 8u + sx);
+            locate_patch_pixel(fr, lp.patch, (int)(vx >> log_gx), (int)(vy >> log_gy), lp.px, lp.py, lp.out_index, lp.store, lp.inside);
+        } else {
+            lp.base_lane = threadIdx.x & 63u;
+            locate_pixel(fr, b, lp.px, lp.py, lp.out_index, lp.store, lp.inside);
+        }
+        return lp;
+    };
+    uint32_t cost_begin = 0;   // ORDERED: when the wave began (the low half of the shader clock, a scalar carried through the kernel)
     if (Traversal::block_size == 64) {
-        // workgroups go to the eight XCDs round robin: keep the waves of a patch (four, or 4 G with sample lanes) on one
-        // XCD (one L2), as the 256-thread form does.  The grid is rounded up to whole groups of 8 patches; the surplus
-        // waves leave here.
         const unsigned int log_waves = 2u + log_gx + log_gy;
-        const unsigned int b = block_index, k = b >> 3, slot = ((k >> log_waves) << 3) + (b & 7u), wave = k & ((1u << log_waves) - 1u);
+        const unsigned int k = block_index >> 3, slot = ((k >> log_waves) << 3) + (block_index & 7u);
         if (slot >= fr.total_patches)
             return;
-        // heaviest patches first (capi.hip: DispatchOrder): which patch this slot of the launch renders, and when the wave
-        // began (two 32-bit scalars carried through the kernel: the patch and the low half of the shader clock)
-        unsigned int patch = slot;
-        if (ORDERED) {
-            patch = fr.dispatch_order ? fr.dispatch_order[slot] : slot;
-            cost_patch = fr.dispatch_cost ? patch : 0xffffffffu;      // (only some launches report: capi.hip)
-            if (fr.dispatch_cost)
-                cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
-        }
-        // the patch as (16 gx) x (16 gy) lane positions, cut into 8x8 wave tiles: position (vx, vy) is sample
-        // (vy % gy) * gx + vx % gx of pixel (vx / gx, vy / gy)
-        const unsigned int lane = threadIdx.x, tiles_across = 2u << log_gx;
-        const unsigned int vx = (wave & (tiles_across - 1u)) * 8u + (lane & 7u), vy = (wave >> (1u + log_gx)) * 8u + (lane >> 3);
-        const unsigned int sx = vx & ((1u << log_gx) - 1u), sy = vy & ((1u << log_gy) - 1u);
-        sub = (sy << log_gx) | sx;
-        base_lane = lane - (sy * 8u + sx);
-        locate_patch_pixel(fr, patch, (int)(vx >> log_gx), (int)(vy >> log_gy), px, py, out_index, store, inside);
-    } else
-        locate_pixel(fr, block_index, px, py, out_index, store, inside);
+        if (ORDERED && fr.dispatch_cost)
+            cost_begin = (uint32_t)__builtin_amdgcn_s_memtime();
+    }
+    const LanePixel first = locate(false);
 
     RayCounters rc = {0, 0, 0, 0, 0, 0, 0};
     const V3 light = mk(fr.light_dir[0], fr.light_dir[1], fr.light_dir[2]);
@@ -115,13 +145,14 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     V3 sum = mk(0, 0, 0);
     float channel_sum = 0.0f, channel_sum2 = 0.0f;   // sample lanes: this lane's colour channel (lane 0 of a pair: also blue)
     for (int s0 = 0; s0 < samples; s0 += (int)G) {
-        const int s = s0 + (int)sub;
-        const bool has_sample = inside && s < samples;
+        const LanePixel at = s0 == 0 ? first : locate(true);
+        const int s = s0 + (int)at.sub;
+        const bool has_sample = at.inside && s < samples;
         // primary ray (vs:39-60, fs:619), sub-pixel pattern of the oracle
         const float ox = ((float)s + 0.5f) / fn;
         const float oy = (float)__brev((unsigned int)s) * 2.3283064365386963e-10f + 0.5f / fn;
-        const float u = divide_by_shared((float)px + ox, by_width);
-        const float v = divide_by_shared((float)py + oy, by_height);
+        const float u = divide_by_shared((float)at.px + ox, by_width);
+        const float v = divide_by_shared((float)at.py + oy, by_height);
         const V3 eye = unit_of_eye(mk(fr.image_plane_width * (u - 0.5f), fr.image_plane_width * (v - 0.5f) * fr.aspect, -1.0f), eye_in_range);
         V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
         V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
@@ -159,6 +190,17 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                 object_specular = sh.object_specular;
             }
             if (has_diffuse) {                                    // uniform
+                // What the diffuse term needs of this hit is formed in FRONT of the shadow traversal -- the cosine (one word
+                // instead of the normal) and modulation * diff, the first product of fs:571's modulation * diffuse * irradiance
+                // -- and the ray moves on to its next bounce there too: across the shadow traversal a lane then carries
+                // accumulated, that product, the cosine and the next ray (16 words instead of 18 + the old ray)
+                const float lcos = sel_max(0.0f, dot3(n, light));
+                const V3 md = modulation * diff;
+                if (shade) {
+                    modulation = modulation * object_specular;
+                    P = P2;
+                    D = R;
+                }
                 bool lit = true;
                 if (fr.cast_shadows) {                            // uniform
                     Hit shadow{kFar, -1.0f, 0.0f, 0.0f};
@@ -167,14 +209,12 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                     lit = shadow.t >= kFar;
                 }
                 if (shade) {
-                    const float lcos = sel_max(0.0f, dot3(n, light));
                     V3 irradiance = mk(0, 0, 0);
                     if (lit)
                         irradiance = irradiance + mk(1.0f, 1.0f, 1.0f) * lcos;
-                    accumulated = accumulated + modulation * diff * irradiance;
+                    accumulated = accumulated + md * irradiance;
                 }
-            }
-            if (shade) {
+            } else if (shade) {
                 modulation = modulation * object_specular;
                 P = P2;
                 D = R;
@@ -192,15 +232,16 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             // this round's G radiances of every pixel, through levels 0-2 of the wave's stack columns (the stacks are
             // empty between traversals), then added in sample order: lane `sub` of a pixel sums channel `sub`
             // (of a pair of lanes, lane 0 sums red and blue); the other lanes of the pixel add along, unused
+            const LanePixel me = locate(true);
             uint32_t *lds = pool.stack - threadIdx.x;
             lds[threadIdx.x] = __float_as_uint(radiance.x);
             lds[64u + threadIdx.x] = __float_as_uint(radiance.y);
             lds[128u + threadIdx.x] = __float_as_uint(radiance.z);
             __syncthreads();   // one wave: orders the exchange for the compiler, costs nothing
-            const unsigned int channel = sub < 3u ? sub : 2u;
+            const unsigned int channel = me.sub < 3u ? me.sub : 2u;
             const int valid = min((int)G, samples - s0);
             for (int k = 0; k < valid; k++) {
-                const unsigned int src = base_lane + (((unsigned int)k >> log_gx) << 3) + ((unsigned int)k & ((1u << log_gx) - 1u));
+                const unsigned int src = me.base_lane + (((unsigned int)k >> log_gx) << 3) + ((unsigned int)k & ((1u << log_gx) - 1u));
                 channel_sum = channel_sum + __uint_as_float(lds[channel * 64u + src]);
                 if (G == 2u)
                     channel_sum2 = channel_sum2 + __uint_as_float(lds[128u + src]);
@@ -208,6 +249,7 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             __syncthreads();
         }
     }
+    const LanePixel me = locate(true);
     if (G > 1u) {
         // sum / n and the tone map are per channel (fs:636-640); the pixel's first lane collects the three and stores
         float c0 = channel_sum / fn, c2 = channel_sum2 / fn;
@@ -216,26 +258,26 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             c2 = filmic(c2);
         }
         uint32_t *lds = pool.stack - threadIdx.x;
-        if (sub < 3u)
-            lds[sub * 64u + base_lane] = __float_as_uint(c0);
-        if (G == 2u && sub == 0u)
-            lds[128u + base_lane] = __float_as_uint(c2);
+        if (me.sub < 3u)
+            lds[me.sub * 64u + me.base_lane] = __float_as_uint(c0);
+        if (G == 2u && me.sub == 0u)
+            lds[128u + me.base_lane] = __float_as_uint(c2);
         __syncthreads();
-        if (sub == 0u && store)
-            out[out_index] = inside ? make_float4(__uint_as_float(lds[threadIdx.x]), __uint_as_float(lds[64u + threadIdx.x]),
-                                                  __uint_as_float(lds[128u + threadIdx.x]), 1.0f)
-                                    : make_float4(0, 0, 0, 0);
+        if (me.sub == 0u && me.store)
+            out[me.out_index] = me.inside ? make_float4(__uint_as_float(lds[threadIdx.x]), __uint_as_float(lds[64u + threadIdx.x]),
+                                                        __uint_as_float(lds[128u + threadIdx.x]), 1.0f)
+                                          : make_float4(0, 0, 0, 0);
     } else {
         V3 result = (ONE_SAMPLE || fr.spp == 1) ? sum : sum / fn;
         if (fr.tonemap)
             result = mk(filmic(result.x), filmic(result.y), filmic(result.z));
-        if (store)
-            out[out_index] = inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
+        if (me.store)
+            out[me.out_index] = me.inside ? make_float4(result.x, result.y, result.z, 1.0f) : make_float4(0, 0, 0, 0);
     }
-    if (ORDERED && cost_patch != 0xffffffffu && (threadIdx.x & 63u) == 0u) {
+    if (ORDERED && fr.dispatch_cost && (threadIdx.x & 63u) == 0u) {
         // the wave's running time in units of 64 shader-clock ticks (32-bit difference: good for 1.7 s): its patch keeps the
         // longest of its waves' (and frames')
-        atomicMax(fr.dispatch_cost + cost_patch, ((uint32_t)__builtin_amdgcn_s_memtime() - cost_begin) >> 6);
+        atomicMax(fr.dispatch_cost + me.patch, ((uint32_t)__builtin_amdgcn_s_memtime() - cost_begin) >> 6);
     }
 #ifdef SHRAY_DIAGNOSTICS
     if (counters && (threadIdx.x & 63u) == 0) {

@@ -406,7 +406,15 @@ int shray_dist_create(shray_scene *scene, const shray_dist_config *config, const
         std::unique_ptr<RcclTransport> t(new RcclTransport);
         ncclUniqueId id;
         memcpy(&id, transport_arg, sizeof(id));
+        // one line per rank on stderr in front of and behind the collective start-up: a run that hangs in it says where
+        // (the first contact of several GPUs has never been observed: VERDICT round 4)
+        const auto t0 = std::chrono::steady_clock::now();
+        fprintf(stderr, "shray_dist_create: rank %d of %d on device %d: ncclCommInitRank ...\n", r.rank, r.world, d->device);
+        fflush(stderr);
         NCCL_TRY(ncclCommInitRank(&t->comm, r.world, id, r.rank));
+        fprintf(stderr, "shray_dist_create: rank %d of %d: communicator up after %.3f s\n", r.rank, r.world,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        fflush(stderr);
         d->transport = std::move(t);
     } else if (config->transport == SHRAY_DIST_LOOPBACK) {
         shray_dist_hub *hub = (shray_dist_hub *)transport_arg;

@@ -304,6 +304,38 @@ def test_bench_launches_its_own_ranks(gpu, tmp_path):
     assert bad.returncode != 0
 
 
+def test_bench_launches_four_ranks_and_survives_a_stalled_one(gpu):
+    """The launcher form with more ranks, and the first-contact guard.  Four ranks share this box's one
+    GPU (with the test process that is five processes on the card; the pool allows six, so the N = 8 form cannot be rehearsed
+    here): uneven tile shares, a step of 8 frames, both root modes, every assembled frame verified.  Then the same command with
+    rank 1 stalled in front of the communicators -- what a hung ncclCommInitRank looks like to the other ranks: the run ends
+    within its --rank-timeout with the one-line record, a non-zero exit code and no process left."""
+    import json
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SHRAY_BENCH_ONE_GPU="1", SHRAY_BENCH_TRANSPORT="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "8", "--warmup", "2", "--trials", "1",
+           "--width", "640", "--height", "360"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), run.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["value"] > 0 and line["frames_mismatched"] == 0 and line["frames_verified"] >= 16
+    assert line["alt_root_mode"]["mode"] == "root0" and line["alt_root_mode"]["value"] > 0
+    t0 = time.time()
+    stalled = subprocess.run(cmd + ["--rank-timeout", "45"], env=dict(env, SHRAY_BENCH_STALL_RANK="1"), capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert stalled.returncode != 0
+    records = [ln for ln in stalled.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(records) == 1, stalled.stdout
+    record = json.loads(records[0])
+    assert record["error"] == "rank timeout" and record["n_gpus"] == 4 and record["value"] is None
+    assert "communicator" in record["where"] or "process" in record["where"], record
+    assert took < 45 + 150, took
+
+
 def _gloo_worker(rank, world_size, port, mode, out_path):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -229,3 +229,40 @@ def test_assemble_numpy_handles_rgb_and_rgba(pkg):
     a = multigpu.assemble_tiles([p.reshape(-1) for p in parts4], w, h, tw, th)
     b = multigpu.assemble_tiles([np.ascontiguousarray(p[..., :3]).reshape(-1) for p in parts4], w, h, tw, th, channels=3)
     assert np.array_equal(a, b)
+
+
+def _bench_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_a_stalled_rank_ends_in_the_timeout_record():
+    """`python bench.py --gpus 2` whose ranks never come back must not hang its caller: within the
+    --rank-timeout budget the run ends with ONE line {"error": "rank timeout", ...} on stdout and a non-zero exit code.  Both forms
+    run without a GPU, because the ranks stall in front of their first GPU call (SHRAY_BENCH_STALL_AT=start):
+      * the ranks' own watchdogs (a timer thread per rank; what also guards a run some other launcher started): rank 0 prints
+        the record and the ranks leave with os._exit(124);
+      * the parent's budget alone (the ranks' watchdogs off): it kills the child's process group and descendants, prints the
+        record itself and returns 124."""
+    import json
+    import subprocess
+    import time
+    bench = os.path.join(ROOT, "bench.py")
+    for knobs, want_rc in ((dict(), None), (dict(SHRAY_BENCH_NO_RANK_WATCHDOG="1", SHRAY_BENCH_PARENT_SLACK="2"), 124)):
+        env = _bench_env(SHRAY_BENCH_STALL_RANK="all", SHRAY_BENCH_STALL_AT="start", **knobs)
+        t0 = time.time()
+        run = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--rank-timeout", "8"],
+                             env=env, capture_output=True, text=True, timeout=240)
+        took = time.time() - t0
+        assert run.returncode != 0 and (want_rc is None or run.returncode == want_rc), (run.returncode, run.stderr[-2000:])
+        lines = [ln for ln in run.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, run.stdout
+        record = json.loads(lines[0])
+        assert record["error"] == "rank timeout" and record["n_gpus"] == 2 and record["value"] is None and record["timeout_s"] == 8
+        assert took < 120, took
+        # nothing of the run is left behind
+        time.sleep(0.5)
+        import psutil
+        left = [p for p in psutil.process_iter(["cmdline"]) if p.info["cmdline"] and bench in p.info["cmdline"] and "--rank-timeout" in p.info["cmdline"]]
+        assert not left, [p.info["cmdline"] for p in left]

@@ -136,23 +136,46 @@ def launch_ranks(n, budget):
     (--rank-timeout): a communicator that never comes up or an exchange that never ends must not hang the caller -- on expiry
     the child's process group and all its descendants are killed, ONE line {"error": "rank timeout", ...} goes to stdout and
     the exit code is 124."""
+    import random
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd), f"(budget {budget:.0f} s)")
-    # the ranks' own watchdogs (arm_watchdog) fire first and say where they were; this budget is the backstop behind them
-    child = subprocess.Popen(cmd, start_new_session=True)
-    try:
-        return child.wait(timeout=budget + float(os.environ.get("SHRAY_BENCH_PARENT_SLACK", "120")) if budget > 0 else None)   # (slack: a fresh box's first `import torch`)
-    except subprocess.TimeoutExpired:
-        log(f"bench.py: the ranks did not finish within {budget:.0f} s: killing them")
-        _kill_tree(child.pid)
-        print(timeout_line(n, budget, "parent: the child process group was killed"), flush=True)
-        return 124
+
+    def free_port():
+        # below the kernel's ephemeral range (32768-60999): a port the kernel hands to nobody between this probe and the
+        # child's listen() a second or two later (a port from bind(0) was taken in that gap once: EADDRINUSE, round 5)
+        for _ in range(64):
+            port = random.randrange(20000, 32000)
+            with socket.socket() as sock:
+                try:
+                    sock.bind(("127.0.0.1", port))
+                    return port
+                except OSError:
+                    continue
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            return sock.getsockname()[1]
+
+    deadline = time.time() + budget + float(os.environ.get("SHRAY_BENCH_PARENT_SLACK", "120"))   # (slack: a fresh box's first `import torch`)
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd), f"(budget {budget:.0f} s)")
+        # the ranks' own watchdogs (arm_watchdog) fire first and say where they were; this budget is the backstop behind them
+        started = time.time()
+        child = subprocess.Popen(cmd, start_new_session=True)
+        try:
+            rc = child.wait(timeout=max(1.0, deadline - time.time()) if budget > 0 else None)
+        except subprocess.TimeoutExpired:
+            log(f"bench.py: the ranks did not finish within {budget:.0f} s: killing them")
+            _kill_tree(child.pid)
+            print(timeout_line(n, budget, "parent: the child process group was killed"), flush=True)
+            return 124
+        # a launcher that died at once (its rendezvous port taken after all) gets one more try on another port; a rank's own
+        # failure takes longer than that (it has imported torch) and is final
+        if rc == 0 or attempt == 1 or time.time() - started > 8.0:
+            return rc
+        log(f"bench.py: the launcher left with code {rc} after {time.time() - started:.1f} s: once more on another port")
+    return rc
 
 
 _watchdog = {"stage": "start-up", "timer": None}

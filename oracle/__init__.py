@@ -61,24 +61,32 @@ def render(desc, env: np.ndarray, params, width: int, height: int, spp: int = 1,
     return out, dict(zip(names, (int(c) for c in counters)))
 
 
-def render_with_paths(desc, env: np.ndarray, params, width: int, height: int, threads: int = 0):
+def render_with_paths(desc, env: np.ndarray, params, width: int, height: int, threads: int = 0, with_decisions: bool = False):
     """render() of a 1 spp plain frame plus its path planes: (frame, counters, path uint32 [h, w], first_triangle int32 [h, w],
     edge_margin float32 [h, w] = the smallest barycentric coordinate of any of the path's hits, env_dy float32 [h, w] = D.y
     of the environment lookup before the oracle clamps it into acos's domain);
     path: bit 2i = bounce i hit a triangle, bit 2i + 1 = that hit was lit, bits 24-27 = bounces that hit, bit 30 = the
     iteration-cap marker (shader_oracle.cpp: g_path_map).  Where the path of a pixel differs from a neighbour's the frame is
-    discontinuous (a silhouette, a shadow edge, a ray that leaves a bounce earlier)."""
+    discontinuous (a silhouette, a shadow edge, a ray that leaves a bounce earlier).
+    with_decisions: a seventh plane, decision_margin float32 [h, w] = how close ANY triangle test of the path, shadow rays
+    included, came to deciding the other way (shader_oracle.cpp: Ctx::decision_margin)."""
     lib = load()
     path = np.zeros((height, width), dtype=np.uint32)
     first = np.full((height, width), -1, dtype=np.int32)
     margin = np.ones((height, width), dtype=np.float32)
     env_dy = np.zeros((height, width), dtype=np.float32)
+    decisions = np.ones((height, width), dtype=np.float32)
     lib.shray_oracle_set_path_map(path.ctypes.data_as(C.c_void_p), first.ctypes.data_as(C.c_void_p), margin.ctypes.data_as(C.c_void_p),
                                   env_dy.ctypes.data_as(C.c_void_p))
+    if with_decisions:
+        lib.shray_oracle_set_decision_map(decisions.ctypes.data_as(C.c_void_p))
     try:
         frame, counters = render(desc, env, params, width, height, 1, threads=threads)
     finally:
         lib.shray_oracle_set_path_map(None, None, None, None)
+        lib.shray_oracle_set_decision_map(None)
+    if with_decisions:
+        return frame, counters, path, first, margin, env_dy, decisions
     return frame, counters, path, first, margin, env_dy
 
 

@@ -277,6 +277,12 @@ struct Ctx {
     float edge_margin = 1.0f;     // the smallest barycentric coordinate of any closest hit of the path (1: no hit)
     float last_edge_margin = 1.0f;
     float env_dy = 0.0f;          // D.y of the last environment lookup, before the clamp of sample_environment
+    // (shray_oracle_set_decision_map) how close any triangle test of the path -- closest-hit AND shadow traversals -- came to
+    // deciding the other way: the smallest distance of a tested point from the triangle's boundary, in barycentric units
+    // (tests whose distance d lies in the leaf's range and in front of the hit so far), and from the ends of that range
+    // relative to d; and the distance of Schlick's pow(x, 5.0) base from zero (negative: NaN, a black pixel)
+    bool track_decisions = false;
+    float decision_margin = 1.0f;
 };
 
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
@@ -291,6 +297,9 @@ uint32_t *g_path_map = nullptr;
 int32_t *g_first_triangle_map = nullptr;
 float *g_edge_margin_map = nullptr;
 float *g_env_dy_map = nullptr;   // D.y of the pixel's environment lookup as the shader hands it to acos (|D.y| > 1: undefined there)
+// decision_margin (Ctx): a shadow ray that grazes an occluder's silhouette, or slips between two triangles, by a few 1e-6 of a
+// barycentric coordinate is lit in one fp32 evaluation and shadowed in another -- round 5's matte frames of the 1M-triangle scene
+float *g_decision_map = nullptr;
 
 // optional per-ray event trace (diagnostics, single-threaded renders only; oracle/tools/wave_sim.cpp reads it):
 // per sample, per traversal: 0xF0 then one byte per node visit = the number of triangle tests that visit ran
@@ -399,6 +408,18 @@ void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surfac
     const vec3 M = cross(e1, theray.D);
     const float det = dot(e0, M);
     const float epsilon = 0.0000001f;
+    if (cx.track_decisions && det != 0.0f) {
+        // diagnostics only: a triangle the ray WOULD hit, whose determinant lies at the rejection threshold of fs:312 (the small
+        // triangles of a 1M-triangle mesh seen at grazing incidence: |det| ~ 1e-7) -- taken by one fp32 evaluation, skipped by another
+        const float closeness = fabsf(fabsf(det) - epsilon) / epsilon;
+        if (closeness < 1e-2f) {
+            const float id = 1.0f / det;
+            const vec3 T0 = theray.P - v0, Q0 = cross(T0, e0);
+            const float d0 = -dot(e1, Q0) * id, u0 = dot(T0, M) * id, w0 = dot(theray.D, Q0) * id;
+            if (!(d0 > hit.t) && !(d0 < r.t0 || d0 > r.t1) && u0 >= 0.0f && w0 >= 0.0f && u0 + w0 <= 1.0f)
+                cx.decision_margin = gl_min(cx.decision_margin, closeness * 1e-3f);
+        }
+    }
     if (det > -epsilon && det < epsilon)
         return;
     const float inv_det = 1.0f / det;
@@ -406,6 +427,20 @@ void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surfac
     const vec3 T = theray.P - v0;
     const vec3 Q = cross(T, e0);
     const float d = -dot(e1, Q) * inv_det;
+    if (cx.track_decisions && !(d > hit.t)) {
+        // diagnostics only (never in a timed or compared render): the distance of this test from each of its decisions
+        const float uu = dot(T, M) * inv_det, vv = dot(theray.D, Q) * inv_det;
+        const float inside = gl_min(gl_min(uu, vv), 1.0f - uu - vv);            // > 0 inside the triangle
+        const float scale = gl_max(fabsf(d), 1e-30f);
+        const float ends = gl_min(fabsf(d - r.t0), fabsf(d - r.t1)) / scale;    // relative distance from the range's ends
+        const bool in_range = !(d < r.t0 || d > r.t1);
+        if (in_range)
+            cx.decision_margin = gl_min(cx.decision_margin, fabsf(inside));
+        // (boxes are inflated by 1e-5 absolute, vectormath.h:189-195: a hit on a box face sits a few 1e-6 of d inside the range, safely
+        // -- d's own rounding is 1e-7 of it; the ends count twenty-fold, so that the classifier's 2e-5 means 1e-6 of d here)
+        if (inside >= 0.0f || fabsf(inside) < 1e-3f)
+            cx.decision_margin = gl_min(cx.decision_margin, 20.0f * ends);
+    }
     if (d > hit.t)
         return;
     if (d < r.t0 || d > r.t1)
@@ -577,6 +612,12 @@ int intersect_and_shade(Ctx &cx, const ray &worldray, vec3 &object_diffuse, vec3
     }
 
     object_specular = f_schlick_vr(V(p.specular_color[0], p.specular_color[1], p.specular_color[2]), worldray.D, reflected.D);
+    if (cx.track_decisions) {
+        // diagnostics only: the base of fs:481's pow(x, 5.0) is 0 +- 1e-8 at normal incidence, and a negative base is NaN (a black
+        // pixel): which side of zero it falls on is a last-bit matter
+        const float base = dot(worldray.D, reflected.D) * .5f + .5f;
+        cx.decision_margin = gl_min(cx.decision_margin, fabsf(base));
+    }
     object_diffuse = V(p.diffuse_color[0], p.diffuse_color[1], p.diffuse_color[2]) * object_color;
     normal = world_normal;
     return 1;
@@ -689,6 +730,8 @@ vec3 trace(Ctx &cx, ray worldray)
     cx.path = 0;
     cx.first_triangle = -1;
     cx.edge_margin = 1.0f;
+    cx.decision_margin = 1.0f;
+    cx.track_decisions = g_decision_map != nullptr;
     for (int i = 0; i < cx.p->bounce_count; i++) {
         ray reflected{};
         vec3 object_diffuse{}, object_specular{}, normal{};
@@ -842,6 +885,8 @@ void shade_pixel(Ctx &cx, int px, int py, int width, int height, int spp, float 
             g_edge_margin_map[(size_t)py * width + px] = cx.edge_margin;
         if (g_env_dy_map)
             g_env_dy_map[(size_t)py * width + px] = cx.env_dy;
+        if (g_decision_map)
+            g_decision_map[(size_t)py * width + px] = cx.decision_margin;
     }
     if (g_visit_map)
     {
@@ -948,6 +993,9 @@ void shray_oracle_set_path_map(uint32_t *path, int32_t *first_triangle, float *e
     g_edge_margin_map = edge_margin;
     g_env_dy_map = env_dy;
 }
+
+// Diagnostics: with the path map set, also the decision-margin plane (Ctx::decision_margin; width * height floats).  NULL to stop.
+void shray_oracle_set_decision_map(float *decision_margin) { g_decision_map = decision_margin; }
 
 // Diagnostics: records the event trace of the next renders (call with threads = 1, whole frame, in pixel order);
 // sample_offsets needs width*height*spp + 1 entries.  shray_oracle_trace_end returns the bytes the trace needed.

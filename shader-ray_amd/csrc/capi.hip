@@ -573,6 +573,13 @@ int dispatch_slot_start(shray_scene *scene, shray_scene::DispatchOrder &d, const
         d.capacity = 0;
         scene->retired.push_back(std::move(r));
     }
+    // (a start that failed behind its allocations -- the memset, an event -- left the slot unused, d.n == 0, WITH buffers of the
+    // capacity that start asked for: no launch has read them; they serve this start only if they are large enough.  ADVICE round 4)
+    if ((d.cost.p || d.ring.p) && d.capacity < patches) {
+        d.cost.release();
+        d.ring.release();
+        d.capacity = 0;
+    }
     // buffers: a retired pair that is large enough and no longer read, else new ones
     for (size_t k = 0; k < scene->retired.size() && !d.cost.p; k++) {
         shray_scene::RetiredOrder &r = *scene->retired[k];

@@ -80,7 +80,8 @@ hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, in
     b.dense = b.one && b.metallic && !deal && !pair && all_plain;
     b.ordered = ordered;
     if (!view_instance)
-        b.lds_bytes = stack_lds_bytes(stack_levels, kBatchBlock, caches_leaves(pair));
+        b.lds_bytes = stack_lds_bytes(stack_levels, kBatchBlock, caches_leaves(pair),
+                                      (parks_state(b.one, deal, pair) && !(tally && tally_full_walk)) ? park_bytes(all_metal) : 0u);
     if (view_instance) {
         if (first.which == 1 || first.which == 2)
             hipLaunchKernelGGL(trace_stack_view_batch_kernel<true>, b.grid, b.block, b.lds_bytes, stream, sc, d_frames, out, frame_stride, stack_levels);

@@ -74,10 +74,22 @@ inline bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which
 // the batch instances whose sequential leaf loop reads its triangles from the wave's leaf cache in LDS (wave_traversal.h)
 constexpr bool caches_leaves(bool pair) { return SHRAY_LEAF_CACHE != 0 && !pair; }
 
-inline size_t stack_lds_bytes(int stack_levels, int block = kBlock, bool cache = false)
+// The multi-sample instances with the plain leaf loop (cache-resident scenes: configs 3 and 5) keep the words of the sample loop
+// that are only touched BETWEEN traversals in LDS, beside the wave's stack, instead of in registers the traversal spills
+// (uniform_driver.h: ParkedState): four words per lane with a zero diffuse colour, five with a diffuse term.  Measured room (round 5,
+// profiles/r05/lds_pad_sweep_configs.txt): a wave of the bunny-class scene (3,904 bytes) has 1,024 bytes to spare at eight waves per
+// SIMD and 1,280 at seven; the 1M-triangle scene's 26-level stacks have none (any padding costs 16 %), and its instances deal.
+#ifndef SHRAY_PARK
+#define SHRAY_PARK 0
+#endif
+constexpr bool parks_state(bool one_sample, bool deal, bool pair) { return SHRAY_PARK != 0 && !one_sample && !deal && !pair; }
+constexpr uint32_t park_bytes(bool metal) { return metal ? 1024u : 1280u; }
+
+inline size_t stack_lds_bytes(int stack_levels, int block = kBlock, bool cache = false, uint32_t park = 0u)
 {
-    // stack columns + per wave: the dealt leaf stage's id table (64 bytes) and, in the instances that have one, the leaf cache
-    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)(block / 64) * (kIdsBytes + (cache ? kCacheBytes : 0u) + SHRAY_LDS_PAD);
+    // stack columns + per wave: the dealt leaf stage's id table (64 bytes), in the instances that have one the leaf cache, and the
+    // parked sample-loop state
+    return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)(block / 64) * (kIdsBytes + (cache ? kCacheBytes : 0u) + park + SHRAY_LDS_PAD);
 }
 
 template <bool DEAL, int BLOCK = kBlock, bool PAIR = false, bool CACHE = false>
@@ -114,8 +126,11 @@ __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const Fram
         frame = rest % frame_count;
         block_index = ((((rest / frame_count) << log_waves) | (k & ((1u << log_waves) - 1u))) << 3) | (b & 7u);
     }
-    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1, ORDERED>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
-                                                                               block_index);
+    // (the full-walk tallying twins, TALLY == 2, run one lane per pixel: a form of their own, nothing parked)
+    constexpr bool PARK = parks_state(ONE_SAMPLE, DEAL, PAIR) && TALLY != 2;
+    float *park = PARK ? reinterpret_cast<float *>(trav.ids + kIdsBytes + (caches_leaves(PAIR) ? kCacheBytes : 0u)) : nullptr;
+    trace_pixels_uniform<Traversal, TALLY != 0, ONE_SAMPLE, METAL, TALLY == 1, ORDERED, PARK>(sc, frames[frame], out + (size_t)frame * frame_stride, counters, trav,
+                                                                                     block_index, park);
 }
 
 // The shape of one batch launch (kernel_stack.hip: launch_stack_batch works it out) and the choices that select an instance.

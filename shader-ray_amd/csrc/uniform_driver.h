@@ -51,10 +51,92 @@ __device__ __forceinline__ V3 unit_of_eye(V3 a, bool components_in_range)
     return mk(div_by_constant4(a.x, length, y, yl), div_by_constant4(a.y, length, y, yl), div_by_constant4(a.z, length, y, yl));
 }
 
-template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false, bool ORDERED = false>
+// PARK (kernel_stack_common.h: parks_state): the words of the sample loop that are only touched BETWEEN traversals live in the
+// wave's LDS slab `park` instead of in registers -- [lane][4] = {x, y, z of the running product `modulation` (zero diffuse colour) or
+// of `accumulated` (with a diffuse term), the lane's channel sum}, and with a diffuse term one more row [lane] for the second
+// channel sum.  A lane reads and writes its own words only; every read sits behind a compiler barrier (the traversal in between
+// writes LDS through other pointers).
+typedef float parked_f3 __attribute__((ext_vector_type(3)));
+template <bool PARK, bool METAL>
+struct ParkedState {
+    float *slab;                       // this lane's four words (PARK only)
+    V3 product = mk(1, 1, 1), sum = mk(0, 0, 0);   // modulation, accumulated: whichever is not parked -- or both
+    float channel = 0.0f, channel2 = 0.0f;
+    __device__ __forceinline__ void begin(float *park)
+    {
+        slab = PARK ? park + 4u * (threadIdx.x & 63u) : nullptr;
+        if (PARK) {
+            slab[3] = 0.0f;
+            if (!METAL)
+                park[256u + (threadIdx.x & 63u)] = 0.0f;
+        }
+    }
+    __device__ __forceinline__ float *second(float *) const { return slab - 4u * (threadIdx.x & 63u) + 256u + (threadIdx.x & 63u); }
+    __device__ __forceinline__ V3 read3() const
+    {
+        asm volatile("" ::: "memory");
+        const parked_f3 v = *reinterpret_cast<const parked_f3 *>(slab);
+        return mk(v.x, v.y, v.z);
+    }
+    __device__ __forceinline__ void write3(V3 v) const
+    {
+        parked_f3 w;
+        w.x = v.x;
+        w.y = v.y;
+        w.z = v.z;
+        *reinterpret_cast<parked_f3 *>(slab) = w;
+    }
+    __device__ __forceinline__ V3 modulation() const { return (PARK && METAL) ? read3() : product; }
+    __device__ __forceinline__ void set_modulation(V3 v)
+    {
+        if (PARK && METAL)
+            write3(v);
+        else
+            product = v;
+    }
+    __device__ __forceinline__ V3 accumulated() const { return (PARK && !METAL) ? read3() : sum; }
+    __device__ __forceinline__ void set_accumulated(V3 v)
+    {
+        if (PARK && !METAL)
+            write3(v);
+        else
+            sum = v;
+    }
+    __device__ __forceinline__ float channel_sum() const
+    {
+        if (!PARK)
+            return channel;
+        asm volatile("" ::: "memory");
+        return slab[3];
+    }
+    __device__ __forceinline__ void set_channel_sum(float v)
+    {
+        if (PARK)
+            slab[3] = v;
+        else
+            channel = v;
+    }
+    __device__ __forceinline__ float channel_sum2() const
+    {
+        if (!(PARK && !METAL))
+            return channel2;
+        asm volatile("" ::: "memory");
+        return *second(nullptr);
+    }
+    __device__ __forceinline__ void set_channel_sum2(float v)
+    {
+        if (PARK && !METAL)
+            *second(nullptr) = v;
+        else
+            channel2 = v;
+    }
+};
+
+template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false, bool ORDERED = false, bool PARK = false>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,
                                                      DeviceCounters *counters, Traversal &pool,
-                                                     unsigned int block_index = 0xffffffffu)   // default: blockIdx.x
+                                                     unsigned int block_index = 0xffffffffu,   // default: blockIdx.x
+                                                     float *park = nullptr)
 {
     if (block_index == 0xffffffffu)
         block_index = blockIdx.x;
@@ -143,7 +225,10 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
     const bool eye_in_range = magnitude_in(fr.image_plane_width, -30, 8) && magnitude_in(fr.aspect, -30, 8);
 
     V3 sum = mk(0, 0, 0);
-    float channel_sum = 0.0f, channel_sum2 = 0.0f;   // sample lanes: this lane's colour channel (lane 0 of a pair: also blue)
+    // sample lanes: this lane's colour channel (lane 0 of a pair: also blue) -- and, in the same object, the sample's
+    // `accumulated` and `modulation`: in registers, or parked in LDS
+    ParkedState<PARK, METAL> kept;
+    kept.begin(park);
     for (int s0 = 0; s0 < samples; s0 += (int)G) {
         const LanePixel at = s0 == 0 ? first : locate(true);
         const int s = s0 + (int)at.sub;
@@ -157,7 +242,8 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         V3 P = xform(fr.camera_matrix, mk(0, 0, 0), 1.0f);
         V3 D = unit(xform(fr.camera_normal_matrix, eye, 0.0f));
 
-        V3 accumulated = mk(0, 0, 0), modulation = mk(1, 1, 1);
+        kept.set_accumulated(mk(0, 0, 0));
+        kept.set_modulation(mk(1, 1, 1));
         bool alive = has_sample;  // still inside trace()'s bounce loop
         bool marker = false;      // returned the bad-hit colour (fs:566-568): no environment term
         for (int bounce = 0; bounce < fr.bounce_count; bounce++) {
@@ -195,9 +281,10 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                 // -- and the ray moves on to its next bounce there too: across the shadow traversal a lane then carries
                 // accumulated, that product, the cosine and the next ray (16 words instead of 18 + the old ray)
                 const float lcos = sel_max(0.0f, dot3(n, light));
+                const V3 modulation = kept.modulation();
                 const V3 md = modulation * diff;
                 if (shade) {
-                    modulation = modulation * object_specular;
+                    kept.set_modulation(modulation * object_specular);
                     P = P2;
                     D = R;
                 }
@@ -212,10 +299,10 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
                     V3 irradiance = mk(0, 0, 0);
                     if (lit)
                         irradiance = irradiance + mk(1.0f, 1.0f, 1.0f) * lcos;
-                    accumulated = accumulated + md * irradiance;
+                    kept.set_accumulated(kept.accumulated() + md * irradiance);
                 }
             } else if (shade) {
-                modulation = modulation * object_specular;
+                kept.set_modulation(kept.modulation() * object_specular);
                 P = P2;
                 D = R;
             }
@@ -224,7 +311,8 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
         if (has_sample && !marker) {
             if (COUNT)
                 rc.env_lookups++;
-            radiance = accumulated + modulation * environment(sc, D);
+            const V3 sky = environment(sc, D);
+            radiance = kept.accumulated() + kept.modulation() * sky;
         }
         if (G == 1u) {
             sum = (ONE_SAMPLE || fr.spp == 1) ? radiance : sum + radiance;
@@ -240,19 +328,23 @@ __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const 
             __syncthreads();   // one wave: orders the exchange for the compiler, costs nothing
             const unsigned int channel = me.sub < 3u ? me.sub : 2u;
             const int valid = min((int)G, samples - s0);
+            float channel_sum = kept.channel_sum(), channel_sum2 = G == 2u ? kept.channel_sum2() : 0.0f;
             for (int k = 0; k < valid; k++) {
                 const unsigned int src = me.base_lane + (((unsigned int)k >> log_gx) << 3) + ((unsigned int)k & ((1u << log_gx) - 1u));
                 channel_sum = channel_sum + __uint_as_float(lds[channel * 64u + src]);
                 if (G == 2u)
                     channel_sum2 = channel_sum2 + __uint_as_float(lds[128u + src]);
             }
+            kept.set_channel_sum(channel_sum);
+            if (G == 2u)
+                kept.set_channel_sum2(channel_sum2);
             __syncthreads();
         }
     }
     const LanePixel me = locate(true);
     if (G > 1u) {
         // sum / n and the tone map are per channel (fs:636-640); the pixel's first lane collects the three and stores
-        float c0 = channel_sum / fn, c2 = channel_sum2 / fn;
+        float c0 = kept.channel_sum() / fn, c2 = (G == 2u ? kept.channel_sum2() : 0.0f) / fn;
         if (fr.tonemap) {
             c0 = filmic(c0);
             c2 = filmic(c2);

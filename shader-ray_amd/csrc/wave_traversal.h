@@ -396,15 +396,6 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     return lane_advance<BLOCK>(t, stack, false, 0u);
 }
 
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ int lane_visit(const SceneView &sc, const FrameView &fr, LaneTraversal &t, uint32_t *stack,
-                                          RayCounters &rc)
-{
-    float4 lo, hi;
-    load_packed_node(sc, node_address(t, t.node), lo, hi);
-    return lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
-}
-
 // 1 / det of triangle_intersect (fs:314).  A determinant the shader goes on with is at least 1e-7 (its early-out, fs:312);
 // below 2^100 (every scene of finite size) the three-instruction reciprocal of exact_div.h IS the correctly rounded
 // quotient; a larger one, or NaN, takes the true division (the wave skips it).  (triangle_candidate applies the early-out
@@ -523,6 +514,10 @@ __device__ __forceinline__ void load_packed_triangle_at(const SceneView &sc, uin
 
 // Node loop: lanes whose state is LT_WALK visit nodes until fewer than `keep_walking` of
 // them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
+// The iteration cap: the counting instances (COUNT: the reference's tallies AND the timed form's tallying twins, TALLY == 1)
+// apply it in front of every visit; the timed instances once per SHRAY_NODE_TURNS visits, so that a capped ray of theirs makes
+// up to SHRAY_NODE_TURNS - 1 node visits the tallying twin does not count (a capped ray's frame is the same marker either way;
+// bench.py's instruction model is off by at most 3 visits per capped ray: 1.9e-5 of config 4's samples, none of the headline's).
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
                                             uint32_t *stack, RayCounters &rc, int keep_walking, bool others_waiting SHRAY_DIAG_PARAM)
@@ -856,8 +851,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
     }
     float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
     uint32_t best = 0xffffffffu;    // no candidate accepted
-    bool unordered = false;         // accepted a candidate whose d is NaN (see above)
-    uint32_t unordered_flag = 0u;   // the same, kept in a vector register by the tied form below
+    uint32_t unordered_flag = 0u;   // accepted a candidate whose d is NaN (see above); set by the tied form below
     SHRAY_DIAG_COUNT(6);
     // bottom-tested, like leaf_stage's loop: group 0's first worker always has a triangle
     uint32_t tri = (uint32_t)sub;
@@ -895,7 +889,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         tri += (uint32_t)G;
         where += (uint32_t)G * 36u;
     } while (wave_ballot(tri < end));
-    if (__builtin_expect(wave_ballot(unordered || unordered_flag != 0u) != 0ull, 0)) {
+    if (__builtin_expect(wave_ballot(unordered_flag != 0u) != 0ull, 0)) {
         asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
         return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
     }

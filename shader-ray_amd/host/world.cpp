@@ -35,7 +35,7 @@ int host_load_threads()
 {
     static const int threads = [] {
         if (const char *s = getenv("SHRAY_LOAD_THREADS"))
-            return std::max(1, atoi(s));
+            return std::min(256, std::max(1, atoi(s)));   // (synthesized normals: every thread walks every face)
         return (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     }();
     return threads;

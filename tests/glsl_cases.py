@@ -29,7 +29,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 FIXTURES = os.path.join(GOLDEN, "glsl_reference")
 
 
-def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, drags=(), move=None, zoom=None, diffuse=None, **more):
+# the path bits (oracle.render_with_paths) a pixel's VALUE depends on when the specular colour is zero: bounce 0's hit and lit
+# bits and the iteration-cap marker -- the later bounces are traversed but weigh nothing (modulation = 0)
+MATTE_PATH_BITS = 0x40000003
+
+
+def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, drags=(), move=None, zoom=None, diffuse=None,
+                specular=None, **more):
     world = pkg.World(path)
     view = world.default_view()
     view.which = which
@@ -44,14 +50,17 @@ def _world_case(pkg, path, env, width, height, material, *, which=0, rotate=0, d
     if zoom is not None:
         view.zoom = view.zoom * zoom
     params = world.frame_params(width, height, view, material=material, diffuse=diffuse)
+    if specular is not None:            # a uniform like any other (ray.cpp:698-704 takes it from the materials table)
+        params.specular_color[:] = specular
     return dict(scene=(world.flatten(), world), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=width,
                 height=height, background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, flips=0, recorded=False, why="",
-                **more)
+                path_bits=0xffffffff, **more)
 
 
 def _hand_case(pkg, hand, env, params, width, height, **more):
     return dict(scene=(hand.desc, hand), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=width, height=height,
-                background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, flips=0, recorded=False, why="", **more)
+                background_mode=0, anisotropy=None, env_storage=0, max_rel=5e-4, bad_fraction=0.03, flips=0, recorded=False, why="",
+                path_bits=0xffffffff, **more)
 
 
 def cases(pkg):
@@ -107,6 +116,19 @@ def cases(pkg):
     #    primary traversal and its shadow rays, and the bunny-class mesh's, are held to 1e-4 off the discontinuities
     out["million_plaster_constant_192"] = _world_case(pkg, helpers.million_obj(), constant, 192, 108, 6)
     out["bunny_plaster_constant_256"] = _world_case(pkg, helpers.bunny_trisrc(), constant, 256, 256, 6, rotate=1)
+    # -- the deep tree on WELL-CONDITIONED pixels (round 5).  Three mirror bounces off sub-pixel
+    #    facets make most of that scene's frame chaotic, and bounce_count is a constant of the shader text (fs:550), which runs
+    #    unmodified; what IS a uniform is the specular colour.  With specular = 0 ("matte": diffuse white, nothing reflected)
+    #    trace() still walks all three bounces, but modulation is 0 after the first: the pixel is the first hit's
+    #    diffuse * max(0, n . l) * lit, tone-mapped -- the closest-hit traversal of the primary ray and the shadow traversal
+    #    behind it (visit order, the 400-visit cap, 10-triangle leaves), a smooth function of the ray everywhere off the
+    #    silhouette and the shadow edges.  Two views (other direction octants, another light), one at four times the pixels.
+    out["million_matte_constant_384"] = _world_case(pkg, helpers.million_obj(), constant, 384, 216, 6, specular=(0.0, 0.0, 0.0))
+    out["million_matte_constant_384"]["path_bits"] = MATTE_PATH_BITS
+    out["million_matte_constant_rotated_192"] = _world_case(pkg, helpers.million_obj(), constant, 192, 108, 6, specular=(0.0, 0.0, 0.0), rotate=2)
+    out["million_matte_constant_rotated_192"]["path_bits"] = MATTE_PATH_BITS
+    out["bunny_matte_constant_256"] = _world_case(pkg, helpers.bunny_trisrc(), constant, 256, 256, 6, specular=(0.0, 0.0, 0.0), rotate=1)
+    out["bunny_matte_constant_256"]["path_bits"] = MATTE_PATH_BITS
     # -- every material of the reference's table (ray.cpp:54-65) and every diffuse colour (:68-73), an object moved off the
     #    origin, a closer camera: the uniforms of ray.cpp:648-704 one by one
     for material in range(7):
@@ -128,6 +150,14 @@ def cases(pkg):
     out["kat_env_only"]["anisotropy"] = 1.0
     out["kat_mirror_quad"] = _hand_case(pkg, single_leaf_scene(kat.mirror_quad()), constant, default_params(pkg, 40, 24, zoom=3.0), 40, 24)
     out["kat_plaster_quad"] = _hand_case(pkg, single_leaf_scene(kat.mirror_quad()), constant, default_params(pkg, 40, 24, zoom=3.0, material=6), 40, 24)
+    # -- a GLSL-undefined corner the frames depend on, pinned by the REFERENCE'S frame: fs:481's pow(x, 5.0) of a
+    #    negative base.  Normals are stored as fp16 and never renormalized (ray.cpp:474, fs:288-295); one a tenth of a per cent too
+    #    long (1 + 2^-10, exact in fp16) makes reflect() return a vector longer than 1 and the base 1 - |n|^2 cos^2 negative within
+    #    2.5 degrees of normal incidence: this driver's pow gives NaN there, the pixel ends black through max(0, c - .004) -- and so do
+    #    the oracle and the kernels (trace_common.h: pow5).  A disc of black pixels in the middle of the mirror.
+    long_normals = np.tile(np.asarray([0.0, 0.0, 1.0 + 2.0 ** -10], np.float32), (6, 1))
+    out["kat_long_normal_mirror"] = _hand_case(pkg, single_leaf_scene(kat.mirror_quad(), long_normals), constant,
+                                               default_params(pkg, 40, 24, zoom=3.0), 40, 24)
     out["kat_iteration_cap_401"] = _hand_case(pkg, kat.chain_scene(401), constant, default_params(pkg, 8, 8), 8, 8)
     out["kat_iteration_cap_400"] = _hand_case(pkg, kat.chain_scene(400), constant, default_params(pkg, 8, 8), 8, 8)
     tris = [[[-5, -5, -float(k)], [5, -5, -float(k)], [0, 5, -float(k)]] for k in range(10)] + [[[-5, -5, 1.0], [5, -5, 1.0], [0, 5, 1.0]]]

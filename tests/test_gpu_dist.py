@@ -332,7 +332,8 @@ def test_bench_launches_four_ranks_and_survives_a_stalled_one(gpu):
     assert len(records) == 1, stalled.stdout
     record = json.loads(records[0])
     assert record["error"] == "rank timeout" and record["n_gpus"] == 4 and record["value"] is None
-    assert "communicator" in record["where"] or "process" in record["where"], record
+    # (over gloo the callback transport is made without a collective: rank 0 gets as far as the first exchange and waits there)
+    assert any(word in record["where"] for word in ("communicator", "trials", "process")), record
     assert took < 45 + 150, took
 
 

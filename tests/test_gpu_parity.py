@@ -143,6 +143,51 @@ def test_hand_built_edge_cases(pkg, gpu, oracle_mod):
         scene.close()
 
 
+def test_iteration_cap_phases_on_a_binary_tree(pkg, gpu, oracle_mod):
+    """Kernel 0's TIMED instances compare the visit counter with zero once per four visits (wave_traversal.h: lane_apply_cap),
+    the counting twins and the oracle at every visit; a chain of leaves is not a binary tree and runs on kernel 1 only (above).
+    Here a hand-built BINARY tree (test_oracle_kat.comb_scene: every ray visits all 2 b + 1 nodes of it, per traversal) is
+    rendered with caps of exactly visits - 5 ... visits + 1 -- the ray needs cap + 5 ... cap - 1 visits: every phase of the
+    four-visit block, the exact fit (no marker) and the one-too-many -- for two tree sizes whose visit counts differ modulo 4,
+    through every form of the timed instances: a lone frame (the ordered dealing instance), two and four frames per launch (the
+    throughput form), zero-diffuse and diffuse (the shadow traversal is capped too: an unlit hit), one and four samples (sample
+    lanes), one to three bounces.  Frames bit-identical to the oracle's; the marker exactly where the oracle has it."""
+    import torch
+    import test_oracle_kat as kat
+    env = pkg.scenes.environment_constant((0.5, 0.25, 2.0))
+    W, H = 24, 16
+    stream = torch.cuda.current_stream().cuda_stream
+    marker_seen = clean_seen = 0
+    for branches in (20, 21):                    # 41 and 43 visits per traversal
+        hand = kat.comb_scene(branches)
+        visits = 2 * branches + 1
+        scene = pkg.Scene(hand.desc, env, device=0)
+        scene.set_kernel(0)
+        for material in (0, 6):
+            for spp in (1, 4):
+                for cap in range(visits - 5, visits + 2):
+                    params = default_params(pkg, W, H, material=material)
+                    params.max_bvh_iterations = cap
+                    params.bounce_count = 1 + (cap + branches) % 3
+                    want, cpu = oracle_mod.render(hand.desc, env, params, W, H, spp)
+                    assert (cpu["bad_hits"] > 0) == (cap < visits), (cap, visits, cpu)
+                    marker_seen += cap < visits
+                    clean_seen += cap >= visits
+                    what = f"comb of {branches} branches, material {material}, {spp} spp, cap {cap} of {visits} visits"
+                    got = scene.render(params, W, H, spp)                       # one frame per launch
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), what
+                    for count in (2, 4):                                        # several frames per launch
+                        out = torch.zeros(count, H, W, 4, dtype=torch.float32, device="cuda")
+                        scene.render_batch_into([params] * count, W, H, spp, out.data_ptr(), H * W * 16, stream)
+                        torch.cuda.synchronize()
+                        for k in range(count):
+                            assert np.array_equal(out[k].cpu().numpy().view(np.uint32), want.view(np.uint32)), (what, count, k)
+                    counted, counters = scene.render_counters(params, W, H, spp)  # the counting twin: the oracle's tallies
+                    assert np.array_equal(counted.view(np.uint32), want.view(np.uint32)) and counters == cpu, what
+        scene.close()
+    assert marker_seen >= 40 and clean_seen >= 16
+
+
 def test_triangles_at_the_ends_of_a_leaf_range(pkg, gpu, oracle_mod):
     """fs:327-331 rejects a candidate outside the range the leaf's box test left.  The kernels park BOUNDS of that range
     (round 4, wave_traversal.h: visit_decision) and hold a candidate that is about to be accepted within 2^-19 of an end

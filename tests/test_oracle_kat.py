@@ -206,6 +206,63 @@ def chain_scene(n):
     return HandScene(tri, [[0, 0, 1]] * 3, lo, hi, hm, objs, 0)
 
 
+def thread_tree(neg, pos, axis, root):
+    """The eight (hit, miss) tables of a binary tree given by its branches' children (leaves: -1) and split axes, as
+    world.cpp:231-288 threads them: for direction code c a branch's hit link is its near child (the NEGATIVE child when bit
+    `axis` of c is set, i.e. D[axis] > 0), its miss link the next subtree on the stack; a leaf's two links are that next subtree."""
+    n = len(neg)
+    hm = np.zeros((8, n, 2), np.float32)
+    for code in range(8):
+        def walk(g, after):
+            if neg[g] < 0:
+                hm[code, g] = (after, after)
+                return
+            near, far = (neg[g], pos[g]) if (code >> axis[g]) & 1 else (pos[g], neg[g])
+            hm[code, g] = (near, after)
+            walk(near, far)
+            walk(far, after)
+        walk(root, END)
+    return hm
+
+
+def comb_scene(branches, hit_triangle=True):
+    """A BINARY tree a ray visits node by node: `branches` branch nodes in a row (node 2i), each with a leaf (node 2i + 1) as
+    its negative child and the next branch -- the last one: a final leaf -- as its positive child, every box the same box around
+    the view, so that every ray visits all 2 * branches + 1 nodes.  The last leaf holds one big triangle in front of the camera (the
+    others are empty): a ray that is not capped is shaded, one that needs more than max_bvh_iterations visits is the red
+    marker.  Unlike chain_scene this IS a canonical threaded tree: kernel 0 takes it."""
+    n = 2 * branches + 1
+    neg, pos, axis = [-1] * n, [-1] * n, [2] * n
+    for i in range(branches):
+        neg[2 * i] = 2 * i + 1
+        pos[2 * i] = 2 * i + 2
+    hm = thread_tree(neg, pos, axis, 0)
+    lo = np.tile([-50, -50, -50], (n, 1))
+    hi = np.tile([50, 50, 50], (n, 1))
+    objs = np.zeros((n, 2), np.float32)
+    tri = [[-40, -40, -1.0], [40, -40, -1.0], [0, 40, -1.0]] if hit_triangle else [[100, 100, 100], [101, 100, 100], [100, 101, 100]]
+    objs[n - 1] = (0, 1)
+    return HandScene(tri, [[0, 0, 1]] * 3, lo, hi, hm, objs, 0)
+
+
+def test_comb_tree_visits_and_cap(pkg, oracle_mod):
+    """comb_scene(b): 2 b + 1 visits per traversal; the cap strikes exactly when a traversal needs more than
+    max_bvh_iterations visits (fs:426-438): cap = visits ends normally, cap = visits - 1 is the marker."""
+    env = pkg.scenes.environment_constant((0.5, 0.5, 0.5))
+    hand = comb_scene(20)
+    p = default_params(pkg, 4, 4)
+    p.bounce_count = 1
+    img, c = oracle_mod.render(hand.desc, env, p, 4, 4)
+    assert c["node_visits"] == 16 * 41 and c["bad_hits"] == 0 and c["shaded_hits"] == 16 and c["leaf_visits"] == 16 * 21
+    p.max_bvh_iterations = 41
+    same, c = oracle_mod.render(hand.desc, env, p, 4, 4)
+    assert np.array_equal(same, img) and c["bad_hits"] == 0
+    p.max_bvh_iterations = 40
+    capped, c = oracle_mod.render(hand.desc, env, p, 4, 4)
+    assert c["bad_hits"] == 16 and c["node_visits"] == 16 * 40
+    assert np.allclose(capped[..., :3], filmic64([1.0, 0.0, 0.0]), rtol=1e-6)
+
+
 def test_iteration_cap_gives_the_red_marker(pkg, oracle_mod):
     """400 iterations without reaching a terminator -> (1,0,0), unmodulated, then tone-mapped
     (raytracer.es.fs:436-438, :497-501, :566-568); exactly 400 nodes still terminate."""

@@ -62,12 +62,39 @@ def own_tolerance(case):
     return case["params"].which != 0 or case["bad_fraction"] >= 1.0
 
 
+def well_floor(name):
+    """The share of a frame that must be WELL-CONDITIONED by the classifier's a-priori criteria (off every change of path, off every
+    shared edge, its 3x3 neighbourhood moving by less than 1e-4 under the perturbations) -- every such pixel is thereby within 1e-4
+    of the reference's.  Set a little below what the cases reach (round 5; VERDICT round 4 found 0.2 / 0.35 far below them): the
+    bunny-class frames 0.84-0.97, the hand-built scenes 0.88-1, the small lobed mesh 0.75-0.96 (64 x 48 frames are one third
+    silhouette and shadow edge), its random views 0.50-0.86, the env-only frame 0.66 (acos x the sky's gradient), the 1M-facet
+    sphere 0.23-0.36: its surface is displaced vertex by vertex, so that even its matte frames (no mirror bounce) change by more
+    than 1e-4 under a turn of 3e-6 rad over most of the frame -- what IS held on that scene is the measured agreement, below."""
+    for prefix, floor in (("bunny", 0.8), ("million", 0.2), ("lobed_random", 0.45), ("kat_env_only", 0.6), ("kat", 0.85), ("lobed", 0.7), ("quads", 0.85)):
+        if name.startswith(prefix):
+            return floor
+    return 0.7
+
+
+def within_floor(name):
+    """The share of a frame's pixels that must BE within 1e-4 of the reference shaders' frame, whatever the classifier says of
+    them -- the direct statement of north_star's bar; a little below what the cases reach."""
+    for prefix, floor in (("million_gold", 0.94), ("million_plaster", 0.985), ("million_matte", 0.98), ("bunny_plaster_sky", 0.97),
+                          ("kat_env_only", 0.97), ("lobed_random", 0.99), ("bunny", 0.9999), ("kat", 1.0), ("lobed", 0.998), ("quads", 0.999)):
+        if name.startswith(prefix):
+            return floor
+    return 0.99
+
+
 def test_oracle_matches_the_reference_shaders(all_cases, oracle_mod):
     """Every plain-view case: a pixel of the oracle's frame further than 1e-4 from the reference shaders' must be
     EXPLAINED (tests/pixel_classifier.py): within one pixel of a change of path -- which bounces hit, which hits were lit,
     the iteration-cap marker -- or where the oracle's own pixel moves as far when its inputs are perturbed by what the
-    driver's acos / atan / arithmetic are measured to be off by.  No unexplained pixel is allowed, in any asserted case; and
-    the well-conditioned pixels, which are thereby all within 1e-4, are most of every frame but the 1M-facet sphere's."""
+    driver's acos / atan / arithmetic are measured to be off by.  No unexplained pixel is allowed, in any asserted case.
+    Round 5 adds what bounds the classifier itself: the share of pixels that ARE within 1e-4 (94 % on the 1M-facet sphere in gold,
+    98.3-98.8 % in plaster and matte, 97.6-100 % everywhere else), the share the classifier calls well-conditioned (well_floor),
+    and how many bad pixels pass through its one unbounded escape -- a neighbourhood that moves by >= 1e-3 under the
+    perturbations --: at most one pixel in a thousand of a fixture frame, reported with the worst of them."""
     import pixel_classifier
     report = []
     asserted = 0
@@ -77,18 +104,22 @@ def test_oracle_matches_the_reference_shaders(all_cases, oracle_mod):
             continue
         verdict = pixel_classifier.classify(oracle_mod, case, want)
         well = verdict["pixels"] - verdict["ill_conditioned_pixels"]
-        report.append(f"{name}: {verdict['bad']} of {verdict['pixels']} pixels outside 1e-4 -- {verdict['discontinuity']} at a change of path, "
-                      f"{verdict['sensitivity']} within the perturbation budget, {verdict['edge']} at a shared edge, {verdict['unexplained']} UNEXPLAINED "
-                      f"(worst {verdict['worst_unexplained']:.1e}); {well} well-conditioned pixels, all within 1e-4"
+        report.append(f"{name}: {verdict['bad']} of {verdict['pixels']} pixels outside 1e-4 ({100.0 - 100.0 * verdict['bad'] / verdict['pixels']:.2f} % within) -- "
+                      f"{verdict['discontinuity']} at a change of path, "
+                      f"{verdict['sensitivity']} within the perturbation budget ({verdict['chaotic_admitted']} of them through the chaotic escape, worst "
+                      f"{verdict['chaotic_admitted_worst']:.1e}), {verdict['edge']} at a shared edge, {verdict['unexplained']} UNEXPLAINED "
+                      f"(worst {verdict['worst_unexplained']:.1e}); {well} well-conditioned pixels ({100.0 * well / verdict['pixels']:.1f} %), all within 1e-4"
                       + (f"   [recorded only: {case['why']}]" if case["recorded"] else ""))
         if case["recorded"]:
             continue
         asserted += 1
         assert verdict["unexplained"] == 0, report[-1]
-        assert well >= (0.2 if name.startswith("million") else 0.35) * verdict["pixels"], report[-1]
+        assert well >= well_floor(name) * verdict["pixels"], report[-1]
+        assert verdict["pixels"] - verdict["bad"] >= within_floor(name) * verdict["pixels"], report[-1]
+        assert verdict["chaotic_admitted"] <= max(1, verdict["pixels"] // 1000), report[-1]
         assert np.all(want[..., 3] == 1.0) and np.all(verdict["frame"][..., 3] == 1.0)
     print("\n".join(report))
-    assert asserted >= 37
+    assert asserted >= 40
     # the debug views (100 x differences of lookup coordinates: fs:135-149, :642-673) and the 5 x 5 supersampled view keep
     # a tolerance of their own
     for name, case in all_cases.items():
@@ -103,7 +134,7 @@ def test_oracle_matches_the_reference_shaders(all_cases, oracle_mod):
         assert agreement(oracle_frame(oracle_mod, all_cases[name]), load_fixture(name)["frame"])[3] < 1e-6, name
     # and the traversal / shading cases (constant environment) hold north_star's 1e-4 on all but a handful of pixels
     for name in ("lobed_gold_constant", "lobed_plaster_constant", "lobed_plaster_constant_rotated", "quads_obj_chrome_constant",
-                 "bunny_gold_constant_256", "bunny_plaster_constant_256"):
+                 "bunny_gold_constant_256", "bunny_plaster_constant_256", "bunny_matte_constant_256"):
         bad, pixels, _, worst = agreement(oracle_frame(oracle_mod, all_cases[name]), load_fixture(name)["frame"])
         assert bad <= 3, (name, bad, worst)
 
@@ -156,6 +187,24 @@ def test_the_marker_and_cap_cases_say_what_the_kats_say(all_cases):
     assert not np.allclose(capped, free)
 
 
+def test_pow_of_a_negative_base_is_what_the_reference_frame_shows(all_cases, oracle_mod):
+    """fs:481's pow(x, 5.0) with x < 0 is undefined in GLSL; the oracle and the kernels return NaN (a black pixel), because the
+    driver behind the fixtures does.  Pinned here against the REFERENCE'S frame, not against the oracle: normals
+    1 + 2^-10 long make the base negative within 2.5 degrees of normal incidence -- the reference's frame has a disc of exactly
+    black pixels in the middle of the mirror, and the oracle's frame is black on the same pixels (the disc's rim, where the base
+    is within 1e-4 of zero, may fall either way)."""
+    case = all_cases["kat_long_normal_mirror"]
+    want = load_fixture("kat_long_normal_mirror")["frame"]
+    got = oracle_frame(oracle_mod, case)
+    black = lambda frame: np.all(frame[..., :3] == 0.0, axis=-1)   # noqa: E731
+    h, w = case["height"], case["width"]
+    assert black(want)[h // 2, w // 2] and black(want)[h // 2 - 1, w // 2 - 1] and 4 <= black(want).sum() <= 40, black(want).sum()
+    assert not black(want)[0, 0] and not black(want)[h // 2, 2]
+    assert (black(want) ^ black(got)).sum() <= 2, (black(want).sum(), black(got).sum())
+    both = ~black(want) & ~black(got)
+    assert np.all(np.abs(got - want)[both][:, :3] <= 1e-4 * np.abs(want[both][:, :3]) + 1e-6)
+
+
 def test_the_capped_pixel_of_the_million_triangle_scene_is_the_same_pixel(all_cases, oracle_mod):
     """BASELINE configs[3]'s deep tree runs a few rays into the 400-iteration cap: in the reference's frame and in the
     oracle's the red marker sits on the same pixels, and the oracle's bad-hit counter counts exactly them."""
@@ -184,7 +233,8 @@ def test_live_reference_shader_reproduces_a_fixture(all_cases, oracle_mod):
 
 
 @pytest.mark.parametrize("which", ["configs[1]: gold under the HDR sky", "glazed plaster under the HDR sky", "gold, constant environment",
-                                   "configs[3]'s 1M-triangle OBJ, gold, constant environment"])
+                                   "configs[3]'s 1M-triangle OBJ, gold, constant environment",
+                                   "configs[3]'s 1M-triangle OBJ, matte (zero specular, diffuse white), constant environment"])
 def test_live_reference_shader_at_full_size(pkg, oracle_mod, which):
     """BASELINE's 1920x1080 frames, where the reference's shaders can run (this container: 1.7 s a frame on llvmpipe): the
     same classifier, no unexplained pixel; the figures are printed (pytest -s) and quoted in DESIGN.md section 2."""
@@ -196,9 +246,12 @@ def test_live_reference_shader_at_full_size(pkg, oracle_mod, which):
     million = which.startswith("configs[3]")
     world = pkg.World(helpers.million_obj() if million else helpers.bunny_trisrc())
     env = pkg.scenes.environment_hdr_sky(2048) if "sky" in which else pkg.scenes.environment_constant((0.5, 0.25, 2.0))
-    params = world.frame_params(W, H, material=6 if "plaster" in which else 0)
+    matte = "matte" in which
+    params = world.frame_params(W, H, material=6 if ("plaster" in which or matte) else 0)
+    if matte:    # the first hit's diffuse term alone (glsl_cases.py: the deep tree on well-conditioned pixels)
+        params.specular_color[:] = (0.0, 0.0, 0.0)
     case = dict(scene=(world.flatten(), world), env=np.ascontiguousarray(env, dtype=np.float32), params=params, width=W, height=H,
-                env_storage=0)
+                env_storage=0, path_bits=glsl_cases.MATTE_PATH_BITS if matte else 0xffffffff)
     want, _ = oracle_mod.render_reference_shader(case["scene"][0], case["env"], params, W, H, 0, 1.0)
     verdict = pixel_classifier.classify(oracle_mod, case, want)
     got = verdict["frame"]
@@ -206,9 +259,12 @@ def test_live_reference_shader_at_full_size(pkg, oracle_mod, which):
     print(f"\n{which}, {W}x{H}: {verdict['bad']} of {verdict['pixels']} pixels outside 1e-4 ({100.0 * verdict['bad'] / verdict['pixels']:.3f} %), "
           f"{int((rel > 1e-3).sum())} beyond 1e-3, {int((rel > 1e-2).sum())} beyond 1e-2; {verdict['discontinuity']} at a change of path, "
           f"{verdict['sensitivity']} within the perturbation budget, {verdict['edge']} at a shared edge (of {verdict['edge_candidates']} such pixels), "
-          f"{verdict['unexplained']} unexplained; "
+          f"{verdict['swallowed_by_nan']} black in the reference among chaotic later bounces, {verdict['unexplained']} unexplained; {verdict['chaotic_admitted']} through the chaotic escape (worst {verdict['chaotic_admitted_worst']:.1e}); "
           f"{verdict['pixels'] - verdict['ill_conditioned_pixels']} well-conditioned pixels")
-    assert verdict["unexplained"] == 0
+    assert verdict["unexplained"] == 0 and verdict["swallowed_by_nan"] <= 2
+    # what bounds the classifier (round 5): the pixels that ARE within 1e-4, and the share admitted by the unbounded escape alone
+    assert verdict["pixels"] - verdict["bad"] >= (0.94 if million and not matte else 0.98) * verdict["pixels"]
+    assert verdict["chaotic_admitted"] <= (0.02 if million and not matte else 0.001) * verdict["pixels"]
     if million:
         # the iteration cap's red marker (fs:436-438): the reference's pixels and the oracle's are not all the same ones at
         # this size -- a capped ray sits at the end of 400 visits, any of whose box tests a last bit can turn -- but every

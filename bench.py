@@ -315,15 +315,15 @@ def main():
     from shader_ray_amd import multigpu
 
     tile = multigpu.DEFAULT_TILE
-    # A GPU wants about eight frames' worth of rays in flight, at least two per launch (profiles/r03/loop_shapes.txt); a
+    # A GPU wants about eight frames' worth of rays in flight, at least two per launch (profiles/history/r03/loop_shapes.txt); a
     # rank of N renders 1 / N of every frame, so its launches carry 4 N frames (its tiles of each) over four streams and
-    # buffer sets (profiles/r03/rank_share_shapes.txt: with N frames per launch on two streams one rank of 8 reached 5.5 x
+    # buffer sets (profiles/history/r03/rank_share_shapes.txt: with N frames per launch on two streams one rank of 8 reached 5.5 x
     # of one GPU's rate before any exchange, with 4 N on four 7.6 x) -- never more than the K frames there are
     lanes = max(1, args.frames_in_flight or 4)
     if distributed:
         lanes = min(lanes, 4)      # buffer sets of a shray_dist object
     # A run of fewer than four such steps takes 2 N frames per step instead: its compute side is the same within noise
-    # (profiles/r03/rank_share_steps.txt: a rank of 8 / 4 / 2 needs 0.65-0.73 / 1.24 / 2.44 ms for its share of 20 frames in
+    # (profiles/history/r03/rank_share_steps.txt: a rank of 8 / 4 / 2 needs 0.65-0.73 / 1.24 / 2.44 ms for its share of 20 frames in
     # steps of 2 N against 0.63-0.66 / 1.22 / 2.43 in one), but only the LAST step's exchange is left uncovered by rendering
     # -- 4 of the driver's 20 frames at N = 8 instead of all 20 (9.3 MB per link, 0.09-0.19 ms of 0.9)
     per_step = 4 * world_size if args.steps >= 16 * world_size else 2 * world_size

@@ -12,7 +12,7 @@
 // tone map agree to float rounding (a 256 x 256 frame of the 69k-triangle mesh under a constant environment: largest
 // relative difference 4.4e-6), frames with an environment lookup to 1e-4 on >= 97 % of the pixels and 5e-4 on all but
 // the rare pixel whose hit / shadow decision falls the other way under the GLSL compiler's own pow / atan / acos; at
-// BASELINE's full 1920 x 1080, 99.95 % of configs[1]'s pixels within 1e-4 (profiles/r03/reference_shader_agreement.txt).
+// BASELINE's full 1920 x 1080, 99.95 % of configs[1]'s pixels within 1e-4 (profiles/history/r03/reference_shader_agreement.txt).
 // What the shader text leaves to the GL implementation is fixed here by rule, and recorded rather than asserted
 // against the driver: textureGrad with zero derivatives under 4x anisotropy (level-0 bilinear here: what the driver
 // does at anisotropy 1), the which == 1 filter, operations on NaN (IEEE here), pow of a negative base (x^5 here).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders one BASELINE configuration a few times, one launch at a time; meant to be wrapped by rocprofv3
-(profiles/r04_config_profile.sh).  SCENE=bunny|million WIDTH HEIGHT SPP MATERIAL REPS in the environment."""
+(profiles/r04/r04_config_profile.sh).  SCENE=bunny|million WIDTH HEIGHT SPP MATERIAL REPS in the environment."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

@@ -2,7 +2,7 @@
 """Runs BASELINE config 4 (1M-triangle OBJ, 1920x1080, 4 spp) a few times; meant to be wrapped by
 rocprofv3 (profiles/run_profile.sh style) to read cache counters for the deep-tree scene."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from __graft_entry__ import load_package

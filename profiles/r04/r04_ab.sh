@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5 A/B: bench (throughput form, 200 and 20 steps, + one frame at a time) and configs 3/4/5 of the shipped library
+# round 4 A/B: bench (throughput form, 200 and 20 steps, + one frame at a time) and configs 3/4/5 of the shipped library
 # and of the libraries under _variants/ named on the command line (all of them when none is named); same box, same call
-#   bash profiles/r05_ab.sh [-c configs] [variant ...]     e.g. -c 4  multi7 multi6
+#   bash profiles/r04/r04_ab.sh [-c configs] [variant ...]     e.g. -c 4  multi7 multi6
 CONFIGS=""
 if [ "$1" = "-c" ]; then CONFIGS=$2; shift 2; fi
 LIBS=("")

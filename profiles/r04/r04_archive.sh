@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies what profiles/r04_evidence.sh left under gpurun_out/ to the names profiles/README.md lists
+# copies what profiles/r04/r04_evidence.sh left under gpurun_out/ to the names profiles/README.md lists
 R=profiles/r04
 cp gpurun_out/prof_r04_default/summary.txt $R/default_bench_command_summary.txt
 cp gpurun_out/prof_r04_config4/summary.txt $R/config4_4spp_summary.txt

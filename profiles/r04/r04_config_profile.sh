@@ -1,10 +1,14 @@
 #!/bin/bash
-# rocprofv3 passes (kernel trace, then counter groups, one per pass) of BASELINE config 4 (the 1M-triangle scene, 4 spp)
+# rocprofv3 passes (kernel trace, then counter groups, one per pass) of one configuration rendered one launch at a time:
+#   bash profiles/r04/r04_config_profile.sh <tag> [VAR=value ...]      (profiles/config_probe.py reads SCENE WIDTH HEIGHT SPP MATERIAL)
+# e.g.  bash profiles/r04/r04_config_profile.sh config3 SPP=64 MATERIAL=6
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out/prof_r04_config4; mkdir -p "$OUT"
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 REPS=8
+TAG=$1; shift
+for kv in "$@"; do export "$kv"; done
+REPO=$(pwd); OUT=$REPO/gpurun_out/prof_r04_$TAG; mkdir -p "$OUT"
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 REPS=${REPS:-8}
 cd /tmp
-CMD="python3 $REPO/profiles/config4_probe.py"
+CMD="python3 $REPO/profiles/config_probe.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1; echo "trace pass exit $?"; tail -1 "$OUT/trace.log"
 i=0
 for GROUP in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -16,4 +20,4 @@ for GROUP in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INS
 done
 cd "$REPO"
 python3 profiles/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
-cat "$OUT/summary.txt"
+grep -A28 "PMC counters" "$OUT/summary.txt" | head -40

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: configs only (no bench) for the shipped library and the variants named:  bash profiles/r05_configs_ab.sh 3,4,5 v1 v2 ...
+# round 5: configs only (no bench) for the shipped library and the variants named:  bash profiles/r05/r05_configs_ab.sh 3,4,5 v1 v2 ...
 CONFIGS=$1; shift
 LIBS=("")
 for v in "$@"; do LIBS+=("shader-ray_amd/_variants/libshray_hip_$v.so"); done

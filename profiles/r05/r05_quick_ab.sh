@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the 200-step throughput form only, for the shipped library and the variants named (bash profiles/r05_quick_ab.sh v1 v2 ...)
+# round 5: the 200-step throughput form only, for the shipped library and the variants named (bash profiles/r05/r05_quick_ab.sh v1 v2 ...)
 LIBS=("")
 for v in "$@"; do LIBS+=("shader-ray_amd/_variants/libshray_hip_$v.so"); done
 for lib in "${LIBS[@]}"; do

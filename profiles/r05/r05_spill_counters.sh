@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: what a configuration writes to and fetches from HBM and how many vector-memory instructions it issues, one launch at a
 # time (three rocprofv3 --pmc passes of profiles/config_probe.py, no tracing beside them):
-#   bash profiles/r05_spill_counters.sh <tag> [VAR=value ...]     (SCENE WIDTH HEIGHT SPP MATERIAL, SHRAY_HIP_LIB for a variant)
+#   bash profiles/r05/r05_spill_counters.sh <tag> [VAR=value ...]     (SCENE WIDTH HEIGHT SPP MATERIAL, SHRAY_HIP_LIB for a variant)
 set -u
 TAG=$1; shift
 for kv in "$@"; do export "$kv"; done

@@ -124,7 +124,7 @@ struct shray_scene {
     // A frame's few long-running waves (rays grazing the silhouette, caught between the ears) last as long as a whole
     // frame of average waves; in row-major order many of them start when a launch is almost over, and a launch that is
     // not followed at once by another -- a rank's share of a step on 8 GPUs, the last launches of a short run -- waits
-    // for them with the machine empty (profiles/r03/dispatch_order_ab.txt: a rank's 20-frame share at N = 8 takes 0.64
+    // for them with the machine empty (profiles/history/r03/dispatch_order_ab.txt: a rank's 20-frame share at N = 8 takes 0.64
     // instead of 0.91 ms).  The waves of the launches a re-sort follows (of every one-frame launch) leave their running
     // time in `cost` (per patch, the longest); every few launches a one-workgroup kernel behind the launch, on its
     // stream, turns the costs into the next permutation (launch_dispatch_order); launches take a permutation up once it
@@ -471,7 +471,7 @@ int make_frame_view(const shray_frame_params *p, int width, int height, int spp,
 // wave's idle lanes shortens divergent waves -- fewer instructions, one memory round trip per leaf instead of up
 // to ten -- but the instance holds a second ray's worth of registers: six waves per SIMD instead of eight for the
 // spp == 1 gold instance, five instead of six for the diffuse / shadow-ray ones.  Measured on MI355X
-// (profiles/r02/leaf_stage_ab.txt):
+// (profiles/history/r02/leaf_stage_ab.txt):
 //   * trees larger than an XCD's L2 share (the 1M-triangle scene, 9.4 MB of nodes): rays diverge, the walk is
 //     latency-bound, dealing wins by 10-18 %;
 //   * one spp == 1 frame per launch (latency): the frame ends with a tail of divergent waves, dealing wins by 11 %;
@@ -506,7 +506,7 @@ int dispatch_bulk_class()
 {
     static const int bulk = [] {
         const char *e = getenv("SHRAY_DISPATCH_BULK");
-        return e ? atoi(e) : 1 << 20;    // every class of its own (measured: profiles/r03/dispatch_bulk_ab.txt)
+        return e ? atoi(e) : 1 << 20;    // every class of its own (measured: profiles/history/r03/dispatch_bulk_ab.txt)
     }();
     return bulk;
 }
@@ -646,7 +646,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
         bool plain = scene->kernel_id == 0 || scene->kernel_id == 3;
         for (int k = 0; k < count; k++)
             plain = plain && !(views[k].which == 1 || views[k].which == 2 || views[k].which == 3 || views[k].which == 5);
-        // Where it pays (profiles/r03/dispatch_order_ab.txt): a launch that is not followed at once by more of the same -- one
+        // Where it pays (profiles/history/r03/dispatch_order_ab.txt): a launch that is not followed at once by more of the same -- one
         // frame per launch (a lone frame: 0.54 -> 0.45 ms), a tile set (a rank's share of a multi-GPU step: 0.92 -> 0.74 ms for
         // 20 frames at N = 8; within 3 % either way once steps follow each other without a gap).  Several whole frames per
         // launch over several streams (the N = 1 throughput form) run 6 % SLOWER heaviest-first -- the long divergent waves
@@ -693,7 +693,7 @@ int launch_stack_views(shray_scene *scene, const FrameView *views, int count, fl
                 if (use >= 0)
                     d.last_reader[use] = seq;
                 // only the launches a re-sort follows report their waves' running times: reporting costs a launch 3 % (a late
-                // scalar load of the buffer's address and an atomic per wave, profiles/r03/dispatch_mechanism_ab.txt)
+                // scalar load of the buffer's address and an atomic per wave, profiles/history/r03/dispatch_mechanism_ab.txt)
                 // (the two launches before a re-sort: a loop that alternates long and short steps reports both)
                 // A launch of one frame always reports: its views change from launch to launch and the union of the last few is
                 // the better predictor (0.474 against 0.480 ms on the orbit).

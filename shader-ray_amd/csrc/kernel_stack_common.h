@@ -21,7 +21,7 @@ constexpr int kBlock = 256;
 constexpr int kBatchBlock = 64;
 
 // Waves per SIMD the register allocator must leave room for, per class of instance (-D overrides them for A/B builds:
-// `make variant`).  Measured: profiles/r02/leaf_stage_ab.txt, profiles/r03/dealt_occupancy_ab2.txt, profiles/r04/occupancy_ab.txt.
+// `make variant`).  Measured: profiles/history/r02/leaf_stage_ab.txt, profiles/history/r03/dealt_occupancy_ab2.txt, profiles/r04/occupancy_ab.txt.
 #ifndef SHRAY_MIN_WAVES
 #define SHRAY_MIN_WAVES 8                 // zero-diffuse multi-sample instances with the plain leaf loop (64 registers): config 5's 4K
                                           // 16 spp frame 10.02 / 9.84 ms at 7 / 8 (10.60 at 6), gold 4 spp +3 % (round 4)
@@ -45,8 +45,13 @@ constexpr int kBatchBlock = 64;
 #define SHRAY_MIN_WAVES_VIEW 5            // the shader's debug views and the counting twins (256-thread workgroups, never timed)
 #endif
 #ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN
-#define SHRAY_MIN_WAVES_GENERAL_PLAIN 7   // ... with the plain leaf loop (cache-resident scenes): config 3 15.87 / 14.69 / 14.43 ms at 5 / 6 / 7,
-                                          // plaster 1 spp 6,649 -> 7,082 Mrays/s at 7 (round 4: profiles/r04/multisample_occupancy_ab.txt)
+#define SHRAY_MIN_WAVES_GENERAL_PLAIN 8   // ... with the plain leaf loop (cache-resident scenes), one sample: plaster 1 spp in the throughput form 7,842 ->
+                                          // 7,998 Mrays/s at 8 (round 5: profiles/r05/one_sample_occupancy_ab.txt; round 4 had 6,649 -> 7,082 from 5 to 7)
+#endif
+#ifndef SHRAY_MIN_WAVES_GENERAL_PLAIN_MULTI
+#define SHRAY_MIN_WAVES_GENERAL_PLAIN_MULTI 8   // ... multi-sample (config 3).  Round 5, after the sample loop stopped carrying the lane's
+                                                // pixel: 13.01 / 12.49 / 12.23 ms at 6 / 7 / 8 (profiles/r05/occupancy_ab.txt) -- the eighth
+                                                // wave wins although it costs 32 B more scratch (124 against 92 B per lane)
 #endif
 #ifndef SHRAY_MIN_WAVES_PAIR
 #define SHRAY_MIN_WAVES_PAIR 6
@@ -58,7 +63,8 @@ constexpr int kBatchBlock = 64;
 constexpr int min_waves(bool metal, bool deal, bool one_sample = true)
 {
     return metal ? (deal ? (one_sample ? SHRAY_MIN_WAVES_DEALT : SHRAY_MIN_WAVES_DEALT_MULTI) : SHRAY_MIN_WAVES)
-                 : (deal ? (one_sample ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_MULTI) : SHRAY_MIN_WAVES_GENERAL_PLAIN);
+                 : (deal ? (one_sample ? SHRAY_MIN_WAVES_GENERAL : SHRAY_MIN_WAVES_GENERAL_MULTI)
+                         : (one_sample ? SHRAY_MIN_WAVES_GENERAL_PLAIN : SHRAY_MIN_WAVES_GENERAL_PLAIN_MULTI));
 }
 
 inline bool one_sample(const FrameView &fr) { return fr.spp == 1; }

@@ -24,7 +24,7 @@
 //   BASELINE configuration, that one included (profiles/r04/octant_copies_ab.txt).
 //   PackedTri (36 B, same triangle order as the reference arrays; three 12-byte loads per test)
 //     { v0.xyz } { e0.xyz } { e1.xyz }   e0 = v1 - v0, e1 = v0 - v2
-//     (48-byte records read as three dwordx4 measure 1.5-2 % slower: profiles/r02/leaf_stage_ab.txt)
+//     (48-byte records read as three dwordx4 measure 1.5-2 % slower: profiles/history/r02/leaf_stage_ab.txt)
 //
 // e0 / e1 are the same single fp32 subtractions triangle_intersect performs
 // per test (raytracer.es.fs:304-305), hoisted to scene-creation time.

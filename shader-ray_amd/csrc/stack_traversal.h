@@ -29,7 +29,7 @@ namespace shray {
 constexpr int kStackKeepWalking = SHRAY_KEEP_WALKING;
 // with the dealt leaf stage a leaf stage with few parked lanes is cheap: the node loop yields as soon as ANY lane is parked
 // (64 of 64).  Measured 48 ... 64 for the one-sample instances on the orbit workload in round 3 (+1.3 % at 64,
-// profiles/r03/dealt_keep_walking_ab.txt) and for the multi-sample dealing instance of the 1M-triangle scene in round 4
+// profiles/history/r03/dealt_keep_walking_ab.txt) and for the multi-sample dealing instance of the 1M-triangle scene in round 4
 // (40 / 48 / 56 / 64: 2.49 / 2.43 / 2.44 / 2.40 ms, profiles/r04/dealt_keep_walking_ab.txt)
 #ifndef SHRAY_KEEP_WALKING_DEALT
 #define SHRAY_KEEP_WALKING_DEALT 64

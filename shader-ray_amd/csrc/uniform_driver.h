@@ -9,7 +9,7 @@
 //
 // Multi-sample frames in one-wave workgroups (SAMPLE LANES): with one lane per pixel a wave runs its 64 pixels' spp
 // samples one after another, so the few heavy waves of a frame (the grazing silhouette) run spp times longer than
-// the others and a lone frame is half tail (profiles/r02/leaf_stage_ab.txt section 22).  Here the G = 2^(x+y) <= 32
+// the others and a lone frame is half tail (profiles/history/r02/leaf_stage_ab.txt section 22).  Here the G = 2^(x+y) <= 32
 // samples of a pixel run in a block of 2^x by 2^y neighbouring lanes of the wave's 8x8 lane grid: a 16x16 patch is
 // 4 G waves, a wave is 64 / G pixels x G samples -- the heavy pixels' work is spread over G lanes, and the 64 rays
 // of a wave are closer together.  The shader adds a pixel's samples in order (fs:622-636: ((r0 + r1) + r2) + ...);

@@ -353,7 +353,7 @@ __device__ __forceinline__ bool visit_decision(const LaneTraversal &t, const flo
 // One node visit for a lane in LT_WALK, given the node's two 16-byte words; returns its next state.
 // (A predicated form of the bookkeeping below -- every side effect once, under its own condition: 75 instead of
 // 96 vector instructions per visit in the ISA -- was measured in rounds 1 and 2 and is 3-8 % SLOWER on every
-// workload, profiles/r02/leaf_stage_ab.txt; the branches let the wave skip whole blocks with s_cbranch_execz.)
+// workload, profiles/history/r02/leaf_stage_ab.txt; the branches let the wave skip whole blocks with s_cbranch_execz.)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraversal &t, uint32_t *stack, RayCounters &rc,
                                                  const float4 lo, const float4 hi)

@@ -49,8 +49,8 @@ ORBIT_DRAG = (0.025, 0.010)  # the mouse drag per frame, in window fractions (tr
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # VALU issue peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-instructions / s
-PMC_FILE = os.path.join("profiles", "r04", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
-ISA_COSTS = os.path.join("profiles", "r04", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
+PMC_FILE = os.path.join("profiles", "r05", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
+ISA_COSTS = os.path.join("profiles", "r05", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
 VMEM_MIX = os.path.join("profiles", "r05", "vmem_class_mix.json")  # distinct records per vector-memory instruction, measured (histogram builds)
 WARM_SECONDS = 0.15        # back-to-back frames before the first trial, beyond the W warm-up steps: the GPU's clock ramps
 
@@ -649,28 +649,36 @@ def main():
             probe_waves, probe_visits = 256 * 4 * 7 * 8, 512
             hip = pkg._native.load_hip()
 
-            def probe(spread, nbytes_lane):
+            def probe(spread, nbytes_lane, neighbours=False):
+                """seconds per wave-instruction, chip-wide; neighbours: the lanes that share a record are runs of neighbouring lanes"""
                 sec, nb = C.c_double(), C.c_uint64()
-                pkg._native.check(hip.shray_probe_vector_cache(32768, spread, probe_visits, probe_waves, 0xffffffffffffffff, nbytes_lane,
-                                                               C.byref(sec), C.byref(nb)))
-                return sec.value / (probe_waves * probe_visits * (2 if nbytes_lane == 32 else 1))   # seconds per wave-instruction, chip-wide
+                pkg._native.check(hip.shray_probe_vector_cache(32768, spread | (0x80000000 if neighbours and spread > 1 else 0), probe_visits, probe_waves,
+                                                               0xffffffffffffffff, nbytes_lane, C.byref(sec), C.byref(nb)))
+                return sec.value / (probe_waves * probe_visits * (2 if nbytes_lane == 32 else 1))
 
             vm = roof["vmem"]
             try:
                 mix = json.load(open(os.path.join(ROOT, VMEM_MIX)))
-                per_inst, classes = 0.0, {}
+                per_inst, per_inst_scattered, classes = 0.0, 0.0, {}
                 for kind in mix["kinds"]:
                     for records, share in kind["records_per_instruction"].items():
-                        t = probe(int(records), kind["probe_bytes_per_lane"])
+                        t_near = probe(int(records), kind["probe_bytes_per_lane"], neighbours=True)
+                        t_far = probe(int(records), kind["probe_bytes_per_lane"])
                         classes[f"{kind['name']}:{records}"] = {"share": round(kind["share_of_insts"] * share, 4),
-                                                                 "cu_cycles_per_inst": round(t * 256 * 2.4e9, 2)}
-                        per_inst += kind["share_of_insts"] * share * t
+                                                                 "cu_cycles_per_inst": round(t_near * 256 * 2.4e9, 2),
+                                                                 "cu_cycles_per_inst_scattered": round(t_far * 256 * 2.4e9, 2)}
+                        per_inst += kind["share_of_insts"] * share * t_near
+                        per_inst_scattered += kind["share_of_insts"] * share * t_far
                 floor = probe(1, 32)
-                vm.update({"peak_g": round(1.0 / per_inst / 1e9, 2), "peak_at_one_record_g": round(1.0 / floor / 1e9, 2), "classes": classes,
-                           "mix_source": VMEM_MIX,
-                           "peak_is": "1 / sum over classes (share x seconds per wave-instruction of that class), the classes' costs probed in this "
-                                      "run (shray_probe_vector_cache, pseudo-random lanes per record, 1 MB table); peak_at_one_record is the "
-                                      "pipeline's floor (every lane at one record), the peak rounds 1-4 priced against"})
+                vm.update({"peak_g": round(1.0 / per_inst / 1e9, 2), "peak_scattered_g": round(1.0 / per_inst_scattered / 1e9, 2),
+                           "peak_at_one_record_g": round(1.0 / floor / 1e9, 2), "classes": classes, "mix_source": VMEM_MIX,
+                           "peak_is": "1 / sum over classes (share x seconds per wave-instruction of that class), the classes = the kernel's measured "
+                                      "mix of distinct records per instruction, their costs probed in this run (shray_probe_vector_cache, 1 MB table): "
+                                      "peak_g with the lanes that share a record in runs of neighbouring lanes (a wave is an 8x8 pixel tile: "
+                                      "rays at one node are neighbours), peak_scattered_g with a pseudo-random lane per record (the pipeline's worst "
+                                      "case for that many records), peak_at_one_record_g with every lane at one record (the floor rounds 1-4 priced "
+                                      "against).  frac = insts_per_s / peak_g; frac_scattered is its upper bound.  R5.1 (38 % of these instructions "
+                                      "removed, no gain) says the truth is near frac"})
             except Exception as exc:   # noqa: BLE001
                 vm["mix_source"] = f"{VMEM_MIX} unusable: {exc}"
             if pmc:
@@ -690,6 +698,7 @@ def main():
                                "scalar_mem_insts_per_frame": (pmc.get("smem_insts_per_launch") or 0) / fpl})
                     if vm.get("peak_g"):
                         vm["frac"] = round(mi * frames_per_s / 1e9 / vm["peak_g"], 5)
+                        vm["frac_scattered"] = round(mi * frames_per_s / 1e9 / vm["peak_scattered_g"], 5)
                         vm["frac_at_one_record_peak"] = round(mi * frames_per_s / 1e9 / vm["peak_at_one_record_g"], 5)
                 if pmc.get("hbm_bytes_per_launch"):
                     hb = pmc["hbm_bytes_per_launch"] / fpl

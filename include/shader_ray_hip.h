@@ -212,6 +212,34 @@ int shray_device_flat_describe(const shray_device_flat *flat, shray_scene_desc *
 int shray_device_flat_download(shray_device_flat *flat, shray_scene_desc *desc);
 int shray_device_flat_destroy(shray_device_flat *flat);
 
+/* BVH build on the GPU ----------------------------------------------------- */
+/* Replaces make_bvh (reference bvh.h:17-21, bvh.cpp:288-358; get_best_split :198-247, sah :107-120, partition :249-286,
+ * make_leaf :122-135): the binned-SAH build over a triangle_set's triangles, level by level on the device
+ * (csrc/bvh_build.hip).  The tree, its boxes and the post-build ORDER of the triangles are those of the reference's
+ * depth-first host build, bit for bit (same float expressions, same exchange partition).
+ *   triangle_vertices   3 vertex indices per triangle, in load order (triangle_set::triangles[k].i, triangle-set.h)
+ *   vertex_data         vertex_stride_floats floats per vertex, the position first (geometry.h:34-38: 9 packed floats)
+ *   options             NULL = the reference's defaults (bvh.cpp:28-58: leaf_max 10, max_depth 30, SAH 1 + 4 n)
+ * shray_device_tree_download: the tree as the pre-order arrays of shray_tree_desc -- what shray_host_export_tree gives for a
+ * host-built tree and what shray_flatten_device takes; desc->triangle_vertices is in post-build order, desc->vertex_data the
+ * caller's pointer; *triangle_order (may be NULL) = which load-order triangle sits at each post-build position.  The arrays
+ * stay owned by the object. */
+typedef struct shray_bvh_options {
+    uint32_t struct_size;            /* sizeof(shray_bvh_options) */
+    int32_t max_depth, leaf_max;     /* BVH_MAX_DEPTH, BVH_LEAF_MAX (bvh.cpp:60-79) */
+    float sah_ctrav, sah_cisec;      /* SAH_CTRAV, SAH_CISEC */
+} shray_bvh_options;
+typedef struct shray_bvh_stats {
+    int32_t node_count, leaf_count, max_level, large_leaves;   /* print_bvh_stats, bvh.cpp:83-99 */
+    double device_seconds;           /* the build on the device, without the upload of its inputs and the download of the tree */
+} shray_bvh_stats;
+typedef struct shray_device_tree shray_device_tree;
+int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_count, const float *vertex_data, int32_t vertex_count,
+                           int32_t vertex_stride_floats, const shray_bvh_options *options, shray_device_tree **out_tree);
+int shray_device_tree_download(shray_device_tree *tree, shray_tree_desc *desc, const int32_t **triangle_order);
+int shray_device_tree_stats(const shray_device_tree *tree, shray_bvh_stats *stats);
+int shray_device_tree_destroy(shray_device_tree *tree);
+
 /* Scene ------------------------------------------------------------------ */
 /* Device memory a scene takes besides the reference's own arrays (which stay resident for the literal kernel): 8 x 32 bytes per
  * node (one repacked copy of the tree per ray-direction octant), 36 bytes per triangle, 64 bytes per node for the pair kernel,

@@ -50,6 +50,17 @@ int shray_host_load_world(const char *filename, shray_host_world **out_world);
 void shray_host_free_world(shray_host_world *world);
 int shray_host_get_world_info(const shray_host_world *world, shray_host_world_info *info);
 
+/* load_world() in two steps, for a BVH built by shray_bvh_build_device (shader_ray_hip.h) instead of make_bvh:
+ *   shray_host_load_triangles   parse, shared vertices, normals, centre + extent -- no BVH yet
+ *   shray_host_triangles        what the build takes: 3 vertex indices per triangle in load order, 9 floats per vertex
+ *                               (pointers into the world, valid until it is freed or a tree is adopted)
+ *   shray_host_adopt_tree       installs the tree (pre-order arrays) and the build's triangle order; build_seconds is recorded
+ *                               as the world's BVH time.  -1 if the arrays are not a pre-order binary tree over these triangles. */
+int shray_host_load_triangles(const char *filename, shray_host_world **out_world);
+int shray_host_triangles(shray_host_world *world, const int32_t **triangle_vertices, int32_t *triangle_count, const float **vertex_data,
+                         int32_t *vertex_count);
+int shray_host_adopt_tree(shray_host_world *world, const shray_tree_desc *tree, const int32_t *triangle_order, double build_seconds);
+
 /* get_shader_data() (world.h:95).  The arrays named by *desc stay owned by
  * `world` and valid until it is freed.  One flattening is kept per
  * data_texture_width: asking again for the same width returns the same arrays. */

@@ -16,16 +16,19 @@ from __graft_entry__ import load_package
 pkg = load_package()
 torch.zeros(1, device="cuda")
 rows = []
+BUILD = os.environ.get("SHRAY_TURNAROUND_BUILD", "host")    # "gpu": the BVH by shray_bvh_build_device (csrc/bvh_build.hip)
 for name, path in (("bunny-class trisrc", pkg.scenes.bunny_trisrc()), ("1M-triangle obj", pkg.scenes.million_obj())):
     best = None
     for rep in range(3):
-        t0 = time.perf_counter(); world = pkg.World(path)
+        t0 = time.perf_counter(); world = pkg.World(path, build=BUILD)
         t1 = time.perf_counter(); desc = world.flatten()
         t2 = time.perf_counter(); scene = pkg.Scene(desc, pkg.scenes.environment_constant(), device=0); torch.cuda.synchronize()
         t3 = time.perf_counter()
         row = {"scene": name, "file_MB": round(os.path.getsize(path) / 1e6, 1), "triangles": int(world.triangle_count),
                "parse_s": round(world.info.parse_seconds, 3), "bvh_build_s": round(world.info.build_seconds, 3),
                "flatten_s": round(t2 - t1, 3), "validate_repack_upload_s": round(t3 - t2, 3), "total_s": round(t3 - t0, 3)}
+        if BUILD == "gpu":   # bvh_build_s = upload of the inputs + device build + download of the tree + adopt_tree on the host
+            row["bvh_device_s"] = round(world.bvh_device_seconds, 4)
         scene.close()
         if best is None or row["total_s"] < best["total_s"]:
             best = row
@@ -34,16 +37,23 @@ print(json.dumps(rows))
 ''' % (ROOT, os.path.join(ROOT, "tests"))
 
 out = {}
-for threads in ("1", ""):
+for threads in ("1", "", "gpu"):
     env = dict(os.environ)
-    if threads:
+    env.pop("SHRAY_TURNAROUND_BUILD", None)
+    if threads == "gpu":
+        env["SHRAY_TURNAROUND_BUILD"] = "gpu"
+        env.pop("SHRAY_LOAD_THREADS", None)
+        env.pop("SHRAY_BVH_THREADS", None)
+    elif threads:
         env["SHRAY_LOAD_THREADS"] = threads
         env["SHRAY_BVH_THREADS"] = "0"
     else:
         env.pop("SHRAY_LOAD_THREADS", None)
         env.pop("SHRAY_BVH_THREADS", None)
     text = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, check=True).stdout
-    out["one thread (the reference's way)" if threads else f"the box's threads ({min(os.cpu_count() or 1, 32)} used of {os.cpu_count()})"] = json.loads(text.strip().splitlines()[-1])
+    label = ("the box's threads for the file, the BVH on the GPU (shray_bvh_build_device)" if threads == "gpu" else
+             "one thread (the reference's way)" if threads else f"the box's threads ({min(os.cpu_count() or 1, 32)} used of {os.cpu_count()})")
+    out[label] = json.loads(text.strip().splitlines()[-1])
     print(threads or "all", text.strip().splitlines()[-1], flush=True)
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "scene_turnaround.json")
 json.dump(out, open(path, "w"), indent=1)

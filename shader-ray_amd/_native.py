@@ -93,6 +93,16 @@ class HostWorldInfo(C.Structure):
     ]
 
 
+class BvhOptions(C.Structure):
+    """shray_bvh_options (include/shader_ray_hip.h): the reference's build parameters (bvh.cpp:28-58)."""
+    _fields_ = [("struct_size", C.c_uint32), ("max_depth", C.c_int32), ("leaf_max", C.c_int32), ("sah_ctrav", C.c_float), ("sah_cisec", C.c_float)]
+
+
+class BvhStats(C.Structure):
+    _fields_ = [("node_count", C.c_int32), ("leaf_count", C.c_int32), ("max_level", C.c_int32), ("large_leaves", C.c_int32),
+                ("device_seconds", C.c_double)]
+
+
 # Every symbol include/shader_ray_hip.h declares: (name, restype, argtypes)
 HIP_SYMBOLS = [
     ("shray_abi_version", C.c_int, []),
@@ -114,6 +124,11 @@ HIP_SYMBOLS = [
     ("shray_device_flat_describe", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     ("shray_device_flat_download", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     ("shray_device_flat_destroy", C.c_int, [C.c_void_p]),
+    ("shray_bvh_build_device", C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(BvhOptions),
+                                         C.POINTER(C.c_void_p)]),
+    ("shray_device_tree_download", C.c_int, [C.c_void_p, C.POINTER(TreeDesc), C.POINTER(C.POINTER(C.c_int32))]),
+    ("shray_device_tree_stats", C.c_int, [C.c_void_p, C.POINTER(BvhStats)]),
+    ("shray_device_tree_destroy", C.c_int, [C.c_void_p]),
     ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
     ("shray_render_batch_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -136,6 +151,10 @@ HIP_SYMBOLS = [
 HOST_SYMBOLS = [
     ("shray_host_load_world", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("shray_host_free_world", None, [C.c_void_p]),
+    ("shray_host_load_triangles", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("shray_host_triangles", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float)),
+                                       C.POINTER(C.c_int32)]),
+    ("shray_host_adopt_tree", C.c_int, [C.c_void_p, C.POINTER(TreeDesc), C.POINTER(C.c_int32), C.c_double]),
     ("shray_host_get_world_info", C.c_int, [C.c_void_p, C.POINTER(HostWorldInfo)]),
     ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
     ("shray_host_export_tree", C.c_int, [C.c_void_p, C.POINTER(TreeDesc)]),

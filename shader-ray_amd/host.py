@@ -13,17 +13,48 @@ from . import _native as N
 class World:
     """A loaded scene (`load_world`, reference world.cpp:46) plus its flattened arrays."""
 
-    def __init__(self, filename: str, quiet: bool = True):
+    def __init__(self, filename: str, quiet: bool = True, build: str = "host", options: N.BvhOptions | None = None):
+        """build = "host": make_bvh on the host (bvh.cpp:288-358; sub-trees on the box's threads); "gpu": the same tree built by
+        shray_bvh_build_device (csrc/bvh_build.hip) -- load_triangles, the device build, adopt_tree -- bit-identical arrays."""
         lib = N.load_host()
         lib.shray_host_set_quiet(1 if quiet else 0)
         handle = C.c_void_p()
-        if lib.shray_host_load_world(filename.encode(), C.byref(handle)) != 0 or not handle:
-            raise RuntimeError(f"load_world failed for {filename!r} (see stderr)")
         self._lib = lib
-        self._handle = handle
         self._desc = None
+        self.bvh_device_seconds = None
+        if build == "host":
+            if lib.shray_host_load_world(filename.encode(), C.byref(handle)) != 0 or not handle:
+                raise RuntimeError(f"load_world failed for {filename!r} (see stderr)")
+            self._handle = handle
+        elif build == "gpu":
+            import time
+            if lib.shray_host_load_triangles(filename.encode(), C.byref(handle)) != 0 or not handle:
+                raise RuntimeError(f"load_triangles failed for {filename!r} (see stderr)")
+            self._handle = handle
+            hip = N.load_hip()
+            tv, vd = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+            nt, nv = C.c_int32(), C.c_int32()
+            if lib.shray_host_triangles(handle, C.byref(tv), C.byref(nt), C.byref(vd), C.byref(nv)) != 0:
+                raise RuntimeError("shray_host_triangles failed")
+            then = time.perf_counter()
+            tree_handle = C.c_void_p()
+            if options is not None:
+                options.struct_size = C.sizeof(N.BvhOptions)
+            N.check(hip.shray_bvh_build_device(tv, nt, vd, nv, 9, C.byref(options) if options is not None else None, C.byref(tree_handle)))
+            try:
+                tree, order = N.TreeDesc(), C.POINTER(C.c_int32)()
+                N.check(hip.shray_device_tree_download(tree_handle, C.byref(tree), C.byref(order)))
+                stats = N.BvhStats()
+                N.check(hip.shray_device_tree_stats(tree_handle, C.byref(stats)))
+                self.bvh_device_seconds = stats.device_seconds
+                if lib.shray_host_adopt_tree(handle, C.byref(tree), order, time.perf_counter() - then) != 0:
+                    raise RuntimeError("shray_host_adopt_tree refused the device-built tree")
+            finally:
+                hip.shray_device_tree_destroy(tree_handle)
+        else:
+            raise ValueError(f"build = {build!r}: 'host' or 'gpu'")
         info = N.HostWorldInfo()
-        lib.shray_host_get_world_info(handle, C.byref(info))
+        lib.shray_host_get_world_info(self._handle, C.byref(info))
         self.info = info
 
     def close(self):

@@ -50,6 +50,70 @@ int shray_host_load_world(const char *filename, shray_host_world **out_world)
 
 void shray_host_free_world(shray_host_world *world) { delete world; }
 
+int shray_host_load_triangles(const char *filename, shray_host_world **out_world)
+{
+    if (!filename || !out_world)
+        return -1;
+    *out_world = nullptr;
+    const auto then = std::chrono::steady_clock::now();
+    world_ptr w = load_triangles(filename);
+    if (!w)
+        return -1;
+    auto *hw = new shray_host_world;
+    hw->w = w;
+    hw->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - then).count();
+    *out_world = hw;
+    return 0;
+}
+
+int shray_host_triangles(shray_host_world *world, const int32_t **triangle_vertices, int32_t *triangle_count, const float **vertex_data,
+                         int32_t *vertex_count)
+{
+    if (!world || !world->w || !triangle_vertices || !triangle_count || !vertex_data || !vertex_count)
+        return -1;
+    const triangle_set &mesh = *world->w->triangles;
+    world->tri_vertices.resize(3 * mesh.triangles.size());
+    for (size_t t = 0; t < mesh.triangles.size(); t++)
+        for (int corner = 0; corner < 3; corner++)
+            world->tri_vertices[3 * t + corner] = mesh.triangles[t].i[corner];
+    static_assert(sizeof(vertex) == 9 * sizeof(float), "vertex is nine packed floats: position, colour, normal");
+    *triangle_vertices = world->tri_vertices.data();
+    *triangle_count = (int32_t)mesh.triangles.size();
+    *vertex_data = mesh.vertices.empty() ? nullptr : &mesh.vertices[0].v.x;
+    *vertex_count = (int32_t)mesh.vertices.size();
+    return 0;
+}
+
+int shray_host_adopt_tree(shray_host_world *world, const shray_tree_desc *tree, const int32_t *triangle_order, double build_seconds)
+{
+    if (!world || !world->w || !tree || !triangle_order || tree->struct_size != sizeof(shray_tree_desc))
+        return -1;
+    if (!adopt_tree(world->w, tree->node_count, tree->node_negative, tree->node_positive, tree->node_box, tree->node_direction,
+                    tree->node_start, tree->node_triangles, triangle_order, tree->triangle_count))
+        return -1;
+    world->w->build_seconds = build_seconds;
+    // the statistics make_bvh keeps (print_bvh_stats, bvh.cpp:83-99), from the tree itself
+    bvh_build_stats stats;
+    std::vector<std::pair<const group *, int>> todo(1, {world->w->root, 0});
+    const bvh_build_options &o = bvh_options();
+    while (!todo.empty()) {
+        const auto [g, level] = todo.back();
+        todo.pop_back();
+        stats.node_count++;
+        stats.max_level = std::max(stats.max_level, level);
+        if (g->is_leaf()) {
+            stats.leaf_count++;
+            if (g->count > o.leaf_max && level < o.max_depth)
+                stats.large_leaves++;
+        } else {
+            todo.push_back({g->negative, level + 1});
+            todo.push_back({g->positive, level + 1});
+        }
+    }
+    world->stats = stats;
+    return 0;
+}
+
 int shray_host_get_world_info(const shray_host_world *world, shray_host_world_info *info)
 {
     if (!world || !info)

@@ -137,7 +137,7 @@ world::world() : triangle_count(0), root(nullptr), scene_center(0.0f), scene_ext
 
 world::~world() { delete root; }
 
-world_ptr load_world(const std::string &filename)
+world_ptr load_triangles(const std::string &filename)
 {
     auto w = std::make_shared<world>();
     w->triangles = std::make_shared<triangle_set>();
@@ -192,8 +192,15 @@ world_ptr load_world(const std::string &filename)
     w->scene_extent = sqrtf(farthest_squared) * 2;
     w->extent_seconds = seconds_since(then);
     host_info("Finding scene center and extent: %f seconds\n", w->extent_seconds);
+    return w;
+}
 
-    then = std::chrono::steady_clock::now();
+world_ptr load_world(const std::string &filename)
+{
+    world_ptr w = load_triangles(filename);
+    if (!w)
+        return nullptr;
+    auto then = std::chrono::steady_clock::now();
     reset_bvh_stats();
     w->root = make_bvh(w->triangles, 0, (unsigned int)w->triangle_count);
     w->build_seconds = seconds_since(then);
@@ -201,6 +208,47 @@ world_ptr load_world(const std::string &filename)
     if (bvh_options().verbose && !g_host_quiet)
         print_bvh_stats();
     return w;
+}
+
+// A tree built elsewhere (the GPU build, shray_bvh_build_device) takes make_bvh's place: the triangles go into the order the
+// build left them in, the group tree (group.h:22-40) is made from the pre-order arrays.  What comes out is what make_bvh would
+// have left: leaves compute their boxes from their triangles' corners (group.cpp), branches keep the build's vertex box.
+bool adopt_tree(const world_ptr &w, int node_count, const int *negative, const int *positive, const float *box, const float *direction,
+                const int *start, const int *triangles, const int *triangle_order, int triangle_count)
+{
+    if (!w || !w->triangles || w->root || node_count <= 0 || triangle_count != (int)w->triangles->triangles.size())
+        return false;
+    triangle_set &mesh = *w->triangles;
+    // every triangle once, every leaf range inside the array, children after their parent (pre-order)
+    std::vector<char> seen((size_t)triangle_count, 0);
+    for (int k = 0; k < triangle_count; k++) {
+        if (triangle_order[k] < 0 || triangle_order[k] >= triangle_count || seen[(size_t)triangle_order[k]])
+            return false;
+        seen[(size_t)triangle_order[k]] = 1;
+    }
+    for (int g = 0; g < node_count; g++) {
+        const bool leaf = negative[g] < 0;
+        if (leaf ? (positive[g] >= 0 || start[g] < 0 || triangles[g] < 0 || start[g] + triangles[g] > triangle_count)
+                 : (negative[g] != g + 1 || positive[g] <= negative[g] || positive[g] >= node_count))
+            return false;
+    }
+    std::vector<indexed_triangle> ordered;
+    ordered.reserve((size_t)triangle_count);
+    for (int k = 0; k < triangle_count; k++)
+        ordered.push_back(mesh.triangles[(size_t)triangle_order[k]]);
+    mesh.triangles.swap(ordered);
+    // children before parents: pre-order backwards
+    std::vector<group *> made((size_t)node_count, nullptr);
+    for (int g = node_count - 1; g >= 0; g--) {
+        if (negative[g] < 0)
+            made[(size_t)g] = new group(w->triangles, start[g], (unsigned int)triangles[g]);
+        else
+            made[(size_t)g] = new group(w->triangles, made[(size_t)negative[g]], made[(size_t)positive[g]],
+                                        vec3(direction[3 * g], direction[3 * g + 1], direction[3 * g + 2]),
+                                        box3d(vec3(box[6 * g], box[6 * g + 1], box[6 * g + 2]), vec3(box[6 * g + 3], box[6 * g + 4], box[6 * g + 5])));
+    }
+    w->root = made[0];
+    return true;
 }
 
 scene_shader_data::scene_shader_data()

@@ -51,6 +51,15 @@ typedef std::shared_ptr<world> world_ptr;
 // Returns nullptr (after a message on stderr) on any failure (world.cpp:46-134).
 world_ptr load_world(const std::string &filename);
 
+// load_world in two steps, for a BVH that is built elsewhere (the GPU build of include/shader_ray_hip.h,
+// shray_bvh_build_device): load_triangles is load_world without make_bvh (root stays null); adopt_tree installs a tree given as
+// pre-order arrays (shray_tree_desc's) and puts the triangles into the build's order (triangle_order[k] = the load-order
+// triangle at post-build position k).  False -- and nothing changed -- if the arrays are not a pre-order binary tree over
+// exactly these triangles.
+world_ptr load_triangles(const std::string &filename);
+bool adopt_tree(const world_ptr &w, int node_count, const int *negative, const int *positive, const float *box, const float *direction,
+                const int *start, const int *triangles, const int *triangle_order, int triangle_count);
+
 // Declared by the reference (world.h:65) but never defined there.  Here it
 // renders the world through the HIP layer (shader_ray_hip.h) with the
 // reference's default material and an all-white environment unless one was

@@ -13,6 +13,8 @@
 //                              launch), exchanged over xGMI (RCCL) and assembled -- shader_ray_dist.h.
 //                [-r mode]     with -g: root0 (every frame assembled on GPU 0) or rotate (frame f on GPU f % N; default)
 //                [-t name]     with -g: rccl (default) or loopback (all ranks share GPU 0: rehearsal on a one-GPU box)
+//                [-b where]    the BVH: host (make_bvh, bvh.cpp:288-358; default) or gpu (shray_bvh_build_device: the same tree,
+//                              built on the device -- load_triangles, the device build, adopt_tree)
 //
 // background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
 // (host/background.cpp; the reference decodes image files through FreeImagePlus).
@@ -28,6 +30,7 @@
 #include <vector>
 
 #include "background.h"
+#include "bvh.h"
 #include "frame-params.h"
 #include "shader_ray_dist.h"
 #include "shader_ray_hip.h"
@@ -145,7 +148,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     int width = 512, height = 512, material = 0, diffuse = 0, spp = 1, frames = 1, gpus = 1;
-    std::string out = "color.ppm", dump_prefix, root_mode = "rotate", transport = "rccl";
+    std::string out = "color.ppm", dump_prefix, root_mode = "rotate", transport = "rccl", bvh_where = "host";
     for (int i = 3; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "-o")) out = argv[i + 1];
         else if (!strcmp(argv[i], "-w")) width = atoi(argv[i + 1]);
@@ -158,9 +161,42 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-g")) gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "-r")) root_mode = argv[i + 1];
         else if (!strcmp(argv[i], "-t")) transport = argv[i + 1];
+        else if (!strcmp(argv[i], "-b")) bvh_where = argv[i + 1];
     }
 
-    world_ptr world = load_world(argv[1]);
+    world_ptr world;
+    if (bvh_where == "gpu") {
+        // load_world (world.cpp:46-134) with make_bvh replaced by the device build
+        world = load_triangles(argv[1]);
+        if (world) {
+            const auto build_began = std::chrono::steady_clock::now();
+            const triangle_set &mesh = *world->triangles;
+            std::vector<int32_t> corners(3 * mesh.triangles.size());
+            for (size_t t = 0; t < mesh.triangles.size(); t++)
+                for (int c = 0; c < 3; c++)
+                    corners[3 * t + c] = mesh.triangles[t].i[c];
+            const bvh_build_options &bo = bvh_options();
+            shray_bvh_options options = {sizeof(shray_bvh_options), bo.max_depth, (int32_t)bo.leaf_max, bo.sah_ctrav, bo.sah_cisec};
+            shray_device_tree *built = nullptr;
+            shray_tree_desc tree;
+            const int32_t *order = nullptr;
+            if (shray_bvh_build_device(corners.data(), (int32_t)mesh.triangles.size(), &mesh.vertices[0].v.x, (int32_t)mesh.vertices.size(), 9,
+                                       &options, &built) != SHRAY_OK ||
+                shray_device_tree_download(built, &tree, &order) != SHRAY_OK ||
+                !adopt_tree(world, tree.node_count, tree.node_negative, tree.node_positive, tree.node_box, tree.node_direction, tree.node_start,
+                            tree.node_triangles, order, tree.triangle_count)) {
+                fprintf(stderr, "The BVH build on the GPU failed: %s\n", shray_last_error());
+                return EXIT_FAILURE;
+            }
+            shray_bvh_stats stats;
+            shray_device_tree_stats(built, &stats);
+            shray_device_tree_destroy(built);
+            world->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - build_began).count();
+            host_info("BVH: %f seconds (on the GPU: %f; %d nodes, %d leaves, deepest level %d)\n", world->build_seconds, stats.device_seconds,
+                      stats.node_count, stats.leaf_count, stats.max_level);
+        }
+    } else
+        world = load_world(argv[1]);
     if (!world) {
         fprintf(stderr, "Cannot set up world.\n");
         return EXIT_FAILURE;

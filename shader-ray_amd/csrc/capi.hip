@@ -942,7 +942,18 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
                         pn.a = (1u << (kAxisHotShift + axis)) | (negative_first ? neg : pos);
                         pn.b = negative_first ? pos : neg;
                     }
-                    c[k] = pn;
+                    // the record's words in the order the visit's packed arithmetic wants them in its register pairs
+                    // (packed_layout.h: DeviceNode): { entry.x, entry.y, exit.x, exit.y } { entry.z, exit.z, a, b }
+                    DeviceNode dn;
+                    dn.entry_xy[0] = pn.lo[0];
+                    dn.entry_xy[1] = pn.lo[1];
+                    dn.exit_xy[0] = pn.hi[0];
+                    dn.exit_xy[1] = pn.hi[1];
+                    dn.z[0] = pn.lo[2];
+                    dn.z[1] = pn.hi[2];
+                    dn.a = pn.a;
+                    dn.b = pn.b;
+                    memcpy(&c[k], &dn, sizeof(dn));
                 }
             }
             HIP_TRY(s->packed_nodes.upload(copies.data(), copies.size() * sizeof(PackedNode)));

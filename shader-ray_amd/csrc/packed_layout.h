@@ -12,6 +12,7 @@
 //   On the device the array exists EIGHT times, once per direction octant (round 4; bit k of an octant: D[k] >= 0, the
 //   predicate range_intersect_box picks a box's entry plane by, fs:204-213).  Copy o holds, node for node at the same offset,
 //     lo = { the planes a ray of octant o ENTERS the box by, a' }     hi = { the planes it LEAVES by, b' }
+//     (in memory as DeviceNode below: { entry.x, entry.y, exit.x, exit.y } { entry.z, exit.z, a', b' })
 //     branch: a' = 1 << (29 + split_axis) | name of the child such a ray visits FIRST      b' = name of the other child
 //     leaf  : as above
 //   where a node's NAME is its byte offset in a copy / 8 (below 2^23: shray_scene_create admits 2^21 nodes).  A ray reads
@@ -47,6 +48,18 @@ struct PackedNode {
     uint32_t b;
 };
 static_assert(sizeof(PackedNode) == 32, "PackedNode must be 32 bytes");
+
+// A record of an octant copy as it lies in device memory (round 5): the same eight words as PackedNode, ordered so that the two
+// 16-byte loads of a visit leave { entry.x, entry.y } { exit.x, exit.y } { entry.z, exit.z } in three aligned register pairs --
+// the operands of the visit's six packed fp32 instructions (wave_traversal.h: slab_range_fast), where PackedNode's order took
+// twelve plain ones.  load_packed_node hands the words back in PackedNode's order to everything else.
+struct DeviceNode {
+    float entry_xy[2];
+    float exit_xy[2];
+    float z[2];          // { entry.z, exit.z }
+    uint32_t a, b;
+};
+static_assert(sizeof(DeviceNode) == 32, "DeviceNode must be 32 bytes");
 
 struct PackedTri {
     float v0[3];

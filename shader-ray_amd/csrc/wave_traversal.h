@@ -199,11 +199,14 @@ __device__ __forceinline__ void lane_apply_cap(LaneTraversal &t, int &state)
 // the (scalar) base plus that 32-bit offset, which the load instruction takes as is (SGPR base + VGPR offset) -- no 64-bit
 // add.  (shray_scene_create admits at most 2^21 nodes and 2^24 vertices -- the shader's float32 indices -- so the eight
 // copies end below 2^29 bytes and triangle byte offsets stay far below 2^32.)
+// (the record lies in memory as DeviceNode, packed_layout.h: { entry.x, entry.y, exit.x, exit.y } { entry.z, exit.z, a, b }; it
+// comes back as lo = { entry planes, a }, hi = { exit planes, b } -- names for registers, no instruction)
 __device__ __forceinline__ void load_packed_node(const SceneView &sc, uint32_t at, float4 &lo, float4 &hi)
 {
     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.packed_nodes) + at);
-    lo = p[0];
-    hi = p[1];
+    const float4 q0 = p[0], q1 = p[1];
+    lo = make_float4(q0.x, q0.y, q1.x, q1.z);
+    hi = make_float4(q0.z, q0.w, q1.y, q1.w);
 }
 
 // The same for the lanes of a wave that are executing, when they are all at ONE record (one node, one octant: the top of the tree, coherent primary
@@ -227,9 +230,10 @@ __device__ __forceinline__ void load_packed_node_shared(const SceneView &sc, uin
         asm("v_mov_b64 %0, %1" : "=v"(w1) : "s"(v[1]));
         asm("v_mov_b64 %0, %1" : "=v"(w2) : "s"(v[2]));
         asm("v_mov_b64 %0, %1" : "=v"(w3) : "s"(v[3]));
-        lo = make_float4(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1),
-                         __uint_as_float((uint32_t)(w1 >> 32)));
-        hi = make_float4(__uint_as_float((uint32_t)w2), __uint_as_float((uint32_t)(w2 >> 32)), __uint_as_float((uint32_t)w3),
+        // (DeviceNode's words: w0 = entry.xy, w1 = exit.xy, w2 = { entry.z, exit.z }, w3 = { a, b })
+        lo = make_float4(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w2),
+                         __uint_as_float((uint32_t)w3));
+        hi = make_float4(__uint_as_float((uint32_t)w1), __uint_as_float((uint32_t)(w1 >> 32)), __uint_as_float((uint32_t)(w2 >> 32)),
                          __uint_as_float((uint32_t)(w3 >> 32)));
     } else {
         load_packed_node(sc, node, lo, hi);
@@ -284,12 +288,39 @@ constexpr float kCheckUp = 1.0f + 0x1p-19f, kCheckDown = 1.0f - 0x1p-19f;     //
 // (r1 comes back WITHOUT its clamp to kRangeMax: the visit folds the clamp into its three-operand minimum with hit.t, a leaf
 // that is entered applies it to what it parks)
 // (lo = the entry planes, hi = the exit planes of the ray's octant: no select)
+// Round 5 (R5.7), built, bit-identical, SLOWER, off (-DSHRAY_PK_SLAB=1): the six subtractions and six multiplications as six PACKED
+// fp32 instructions (v_pk_add_f32 with its second source negated, v_pk_mul_f32: IEEE per component, the same values), on register
+// PAIRS -- { entry.x, entry.y }, { exit.x, exit.y }, { entry.z, exit.z } as the record's loads leave them (DeviceNode), { P.x, P.y },
+// { Y.x, Y.y } and { P.z, Y.z } of the ray, the z pair serving both halves of its instructions through op_sel; no pairing moves in
+// the ISA.  Six issue slots fewer per visit -- and the headline 1 % slower, configs 3 / 5 2.3 % (profiles/r05/packed_slab_ab.txt):
+// a packed instruction occupies the VALU as long as the two it replaces (R4.16) and its results arrive later in the visit's
+// dependent chain (subtract -> multiply -> max3 -> compare).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef SHRAY_PK_SLAB
+#define SHRAY_PK_SLAB 0
+#endif
 __device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
+#if SHRAY_PK_SLAB
+    f32x2 e = {lo.x, lo.y}, x = {hi.x, hi.y}, z = {lo.z, hi.z};
+    const f32x2 pxy = {t.P.x, t.P.y}, yxy = {t.Y.x, t.Y.y}, pzyz = {t.P.z, t.Y.z};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e) : "v"(e), "v"(pxy));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(pxy));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(z) : "v"(z), "v"(pzyz));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(yxy));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(yxy));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(z) : "v"(z), "v"(pzyz));
+    // (a bare v_max_f32: fmaxf() of an asm result is canonicalised first -- one more instruction)
+    float first;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(first) : "v"(e.x));
+    r0 = fmaxf(fmaxf(first, e.y), z.x);
+    r1 = fminf(fminf(x.x, x.y), z.y);
+#else
     const float ex = lo.x - t.P.x, ey = lo.y - t.P.y, ez = lo.z - t.P.z;
     const float xx = hi.x - t.P.x, xy = hi.y - t.P.y, xz = hi.z - t.P.z;
     r0 = fmaxf(fmaxf(fmaxf(0.0f, ex * t.Y.x), ey * t.Y.y), ez * t.Y.z);
     r1 = fminf(fminf(xx * t.Y.x, xy * t.Y.y), xz * t.Y.z);
+#endif
 }
 
 // The leaf's exact clipped range (fs:406: the range the leaf's box test left), from the leaf's own record: t.node is

@@ -226,3 +226,61 @@ def test_threaded_loaders_equal_the_serial_loaders(pkg, tmp_path):
         assert _digest_in_a_process(paths, threads) == serial, threads
     assert serial[5] == "!" and "!" not in serial[:5] + serial[6:]      # the truncated record fails the load either way
     assert len(set(serial[3:5])) == 2                                    # (the tricky text is another scene than the plain one)
+
+
+def test_load_triangles_and_adopt_tree(pkg):
+    """load_world in two steps, for a BVH built elsewhere (the GPU build: include/shader_ray_host.h).  Without a GPU: the tree the HOST
+    builder made for a scene, exported (shray_host_export_tree), is adopted by a second world that only loaded the triangles -- with
+    the build's triangle order recovered from the two worlds' vertex indices (the lobed mesh has no two triangles with the same three
+    vertices) -- and flattens to the same arrays; trees that are not pre-order binary trees over exactly these triangles are refused
+    and leave the world as it was."""
+    import ctypes as C
+    N = pkg._native
+    lib = N.load_host()
+    path = os.path.join(helpers.GOLDEN, "lobed_528.trisrc") if hasattr(helpers, "GOLDEN") else os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "golden", "lobed_528.trisrc")
+    built = pkg.World(path)
+    tree = built.export_tree()
+    n, t = tree.node_count, tree.triangle_count
+    after = np.ctypeslib.as_array(tree.triangle_vertices, shape=(t, 3)).copy()
+
+    def fresh():
+        handle = C.c_void_p()
+        assert lib.shray_host_load_triangles(path.encode(), C.byref(handle)) == 0 and handle
+        tv, vd, nt, nv = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int32(), C.c_int32()
+        assert lib.shray_host_triangles(handle, C.byref(tv), C.byref(nt), C.byref(vd), C.byref(nv)) == 0 and nt.value == t
+        return handle, np.ctypeslib.as_array(tv, shape=(t, 3)).copy()
+
+    handle, before = fresh()
+    where = {tuple(row): k for k, row in enumerate(before.tolist())}
+    assert len(where) == t
+    order = np.asarray([where[tuple(row)] for row in after.tolist()], dtype=np.int32)
+    order_p = order.ctypes.data_as(C.POINTER(C.c_int32))
+    # refused: a triangle twice; a tree whose negative child is not the next node
+    twice = order.copy()
+    twice[1] = twice[0]
+    assert lib.shray_host_adopt_tree(handle, C.byref(tree), twice.ctypes.data_as(C.POINTER(C.c_int32)), 0.0) == -1
+    negative = np.ctypeslib.as_array(tree.node_negative, shape=(n,)).copy()
+    branch = int(np.nonzero(negative >= 0)[0][0])
+    saved = tree.node_negative[branch]
+    tree.node_negative[branch] = saved + 1
+    assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.0) == -1
+    tree.node_negative[branch] = saved
+    # adopted: the same flattened arrays and statistics as the world make_bvh built
+    assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.125) == 0
+    info = N.HostWorldInfo()
+    lib.shray_host_get_world_info(handle, C.byref(info))
+    for field in ("node_count", "leaf_count", "max_level", "large_leaves", "triangle_count"):
+        assert getattr(info, field) == getattr(built.info, field), field
+    assert info.build_seconds == 0.125
+    desc = N.SceneDesc()
+    assert lib.shray_host_flatten(handle, 2048, C.byref(desc)) == 0
+    mine, want = pkg.host.desc_arrays(desc), built.arrays()
+    for key, value in want.items():
+        if isinstance(value, np.ndarray):
+            assert np.array_equal(value.view(np.uint32), mine[key].view(np.uint32)), key
+        else:
+            assert value == mine[key], key
+    assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.0) == -1      # a world that has its tree takes no other
+    lib.shray_host_free_world(handle)
+    built.close()

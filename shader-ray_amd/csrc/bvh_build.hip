@@ -600,9 +600,19 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
     }
     const int T = triangle_count, max_nodes = 2 * T;
 
-    hipEvent_t began, ended;
-    BVH_TRY(hipEventCreate(&began));
-    BVH_TRY(hipEventCreate(&ended));
+    struct Events {     // (destroyed on every way out)
+        hipEvent_t began = nullptr, ended = nullptr;
+        ~Events()
+        {
+            if (began)
+                (void)hipEventDestroy(began);
+            if (ended)
+                (void)hipEventDestroy(ended);
+        }
+    } events;
+    BVH_TRY(hipEventCreate(&events.began));
+    BVH_TRY(hipEventCreate(&events.ended));
+    hipEvent_t &began = events.began, &ended = events.ended;
     DeviceArray d_tv, d_vd, d_box, d_bary, d_original, d_node, d_flag, d_below, d_left, d_right, d_scan_temp;
     BVH_TRY(d_tv.alloc((size_t)3 * T * 4));
     BVH_TRY(d_vd.alloc((size_t)vertex_count * vertex_stride_floats * 4));
@@ -714,8 +724,6 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
     BVH_TRY(hipEventSynchronize(ended));
     float ms = 0;
     BVH_TRY(hipEventElapsedTime(&ms, began, ended));
-    (void)hipEventDestroy(began);
-    (void)hipEventDestroy(ended);
 
     std::unique_ptr<shray_device_tree> made(new shray_device_tree);
     made->node_count = total;

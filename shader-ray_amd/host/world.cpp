@@ -226,12 +226,17 @@ bool adopt_tree(const world_ptr &w, int node_count, const int *negative, const i
             return false;
         seen[(size_t)triangle_order[k]] = 1;
     }
+    int covered = 0;   // in pre-order the leaves follow each other through the triangle array: no gap, no overlap
     for (int g = 0; g < node_count; g++) {
         const bool leaf = negative[g] < 0;
-        if (leaf ? (positive[g] >= 0 || start[g] < 0 || triangles[g] < 0 || start[g] + triangles[g] > triangle_count)
+        if (leaf ? (positive[g] >= 0 || start[g] != covered || triangles[g] < 0 || start[g] + triangles[g] > triangle_count)
                  : (negative[g] != g + 1 || positive[g] <= negative[g] || positive[g] >= node_count))
             return false;
+        if (leaf)
+            covered += triangles[g];
     }
+    if (covered != triangle_count)
+        return false;
     std::vector<indexed_triangle> ordered;
     ordered.reserve((size_t)triangle_count);
     for (int k = 0; k < triangle_count; k++)

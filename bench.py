@@ -90,6 +90,72 @@ def cpu_baseline(pkg, desc, env, params, budget_s=12.0):
                       f"{elapsed:.1f} s, CPU oracle with {threads} threads"}
 
 
+LIVE_GROUPS = ["SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_LDS", "FETCH_SIZE", "WRITE_SIZE"]
+
+
+def live_counters(argv_tail, batch, budget_s=100.0):
+    """Hardware counters of the dominant kernel from THIS invocation (VERDICT round 4, weak point 7): after the timed region, rank 0
+    at N = 1 runs this script again as a child process under `rocprofv3 --pmc <group>` (one group per pass, nothing traced beside
+    them; the program itself behind `--`, started as a child, never an exec) in its --counter-child form -- scene load, 2 x ORBIT
+    frames of the timed loop's launches, exit -- and averages each counter over the kernel's launches that carried `batch` frames.
+    Returns (dict like profiles/make_pmc_json.py writes, note) or (None, why not): any failure (no rocprofv3, a pass that
+    does not end within its share of `budget_s`) falls back to the committed counter file."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "rocprofv3 is not on this box"
+    began = time.time()
+    sums, counts = {}, {}
+    kernel = None
+    for group in LIVE_GROUPS:
+        left = budget_s - (time.time() - began)
+        if left < 10.0:
+            return None, f"the counter passes did not fit their {budget_s:.0f} s"
+        out = tempfile.mkdtemp(prefix="shray_pmc_", dir="/tmp")
+        cmd = [tool, "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--counter-child", "--steps", str(2 * ORBIT), "--warmup", "0"] + argv_tail
+        try:
+            run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8"), timeout=left,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"a counter pass ({group}) did not end within {left:.0f} s"
+        if run.returncode != 0:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"a counter pass ({group}) left with code {run.returncode}: {run.stderr[-200:]}"
+        rows = 0
+        for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                name = r.get("Kernel_Name", "")
+                # the timed loop's kernel: the batch kernels of the stack tracer; whole launches only (grid = batch frames' worth)
+                if "trace_stack_batch" not in name:
+                    continue
+                kernel = kernel or name.split("(")[0]
+                key = r["Counter_Name"]
+                sums[key] = sums.get(key, 0.0) + float(r["Counter_Value"])
+                counts[key] = counts.get(key, 0) + 1
+                rows += 1
+        shutil.rmtree(out, ignore_errors=True)
+        if not rows:
+            return None, f"a counter pass ({group}) reported no launch of the tracer's kernel"
+    avg = {k: sums[k] / counts[k] for k in sums}
+    launches = counts.get("SQ_INSTS_VALU", 0)
+    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "FETCH_SIZE", "WRITE_SIZE")
+    if any(k not in avg for k in need) or launches * batch != 2 * ORBIT:
+        return None, f"the counter passes saw {launches} launches of {batch} frames for {2 * ORBIT} frames"
+    return {"kernel": kernel, "counters_per_launch": avg, "launches_averaged": launches,
+            "workload": {"frames_per_launch": batch},
+            "valu_insts_per_launch": avg["SQ_INSTS_VALU"], "lane_util": avg["SQ_THREAD_CYCLES_VALU"] / (avg["SQ_INSTS_VALU"] * 64.0),
+            "vmem_insts_per_launch": avg["SQ_INSTS_VMEM_RD"], "smem_insts_per_launch": avg.get("SQ_INSTS_SMEM"),
+            "hbm_bytes_per_launch": int((2 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024)}, \
+        (f"rocprofv3 --pmc passes of this invocation's own child runs ({len(LIVE_GROUPS)} passes, {launches} launches of {batch} frames = two "
+         f"periods of the orbit each, {time.time() - began:.0f} s)")
+
+
 def algorithmic_ops(counters, costs):
     """Lane-instructions of the shader's own arithmetic for the work the counters describe (profiles/isa_costs.py)."""
     c, k = counters, costs
@@ -229,6 +295,10 @@ def main():
                          "root0 = every frame on rank 0 (gather)")
     ap.add_argument("--rgba-wire", action="store_true", help="N > 1 only: exchange RGBA instead of RGB (alpha is the constant 1)")
     ap.add_argument("--same-view", action="store_true", help="every frame renders the first view of the orbit (round 2's loop)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="N = 1: take the roofline's instruction and byte counts from the committed counter file only (default: "
+                         "measure them in this invocation with short `rocprofv3 --pmc` child runs after the timed region, ~30 s)")
+    ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)   # the child run live_counters() profiles
     ap.add_argument("--rank-timeout", type=float, default=300.0,
                     help="N > 1: wall-clock budget in seconds for the whole multi-rank run; on expiry the ranks are killed, ONE line "
                          '{"error": "rank timeout", ...} is printed and the exit code is 124 (0 = no budget)')
@@ -500,6 +570,11 @@ def main():
                 differing += 0 if torch.equal(frame_outs[0][k * HEIGHT * WIDTH * 4:(k + 1) * HEIGHT * WIDTH * 4], whole) else 1
         return compared, differing
 
+    if args.counter_child:
+        # what live_counters() profiles: exactly `steps` frames of the timed loop's launches (whole periods of the orbit), nothing else
+        run(args.steps)
+        fence()
+        return
     stage("warm-up and timed trials (shray_dist_step: render, pack, grouped exchange, de-interleave)" if distributed else "timed trials")
     trial_s, warm_ms, warm_frames = timed_trials()
     elapsed = sorted(trial_s)[len(trial_s) // 2]
@@ -623,6 +698,7 @@ def main():
                          "concurrent_launches": lanes, "frames_per_launch": batch,
                          "kernel_events": f"{len(kernel_ms)} launches of the timed region bracketed by HIP events on their own streams (every {EVENT_STRIDE}th)"})
             pmc, pmc_note = None, "no counter file"
+            kernel_source_hash = lambda: None   # noqa: E731  (replaced below; a counter file never carries None)
             try:
                 sys.path.insert(0, os.path.join(ROOT, "profiles"))
                 from buildhash import kernel_source_hash
@@ -638,6 +714,27 @@ def main():
                     pmc_note = PMC_FILE + " is for another workload"
             except Exception as exc:   # noqa: BLE001
                 pmc_note = f"{PMC_FILE} unreadable: {exc}"
+            # the counts of THIS invocation where they can be had (the busy counters stay the archived run's: they are not rates)
+            archived = pmc
+            if not args.no_live_counters and os.environ.get("SHRAY_BENCH_LIVE_COUNTERS", "1") != "0":
+                tail = ["--width", str(WIDTH), "--height", str(HEIGHT), "--spp", str(SPP), "--material", str(args.material),
+                        "--kernel", str(args.kernel), "--frames-per-launch", str(batch), "--frames-in-flight", str(lanes)] + \
+                       (["--same-view"] if args.same_view else [])
+                live, live_note = live_counters(tail, batch)
+                if live:
+                    if archived and archived["build_hash"] == kernel_source_hash():
+                        for key in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac_profiled", "wait_frac", "serialized_launch_ms",
+                                    "kernel_trace_avg_us", "valu_mix_per_launch"):
+                            live[key] = archived.get(key)
+                        if live.get("valu_mix_per_launch"):      # (a mix of the archived run's instructions: scale to this count)
+                            scale = live["valu_insts_per_launch"] / archived["valu_insts_per_launch"]
+                            live["valu_mix_per_launch"] = {k: v * scale for k, v in live["valu_mix_per_launch"].items()}
+                        roof["archived_counters_agree"] = {
+                            k: round(live[k] / archived[k], 5) for k in ("valu_insts_per_launch", "vmem_insts_per_launch", "hbm_bytes_per_launch")
+                            if archived.get(k)}
+                    pmc, pmc_note = live, live_note
+                else:
+                    pmc_note += f"; live counters not taken: {live_note}"
             roof["counter_source"] = pmc_note
             # The vector memory pipeline: one per CU (texture addresser + vector L1 + texture data), shared by the CU's four
             # SIMDs.  What it sustains depends on how many distinct records the lanes of an instruction read

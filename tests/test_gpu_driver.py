@@ -4,6 +4,7 @@ readback forms of the C ABI (ray.cpp:760), and BASELINE config 4 at its full siz
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -214,3 +215,31 @@ def test_shader_constants_as_parameters(pkg, gpu, oracle_mod, material):
                 assert np.array_equal(scene.render(params, W, H, spp), got), (overrides, spp, kernel)
     scene.set_kernel(0)
     scene.close()
+
+
+def test_bench_line_carries_the_frozen_roofline_object(gpu):
+    """`python bench.py` (N = 1) prints ONE line whose `roofline` has the round-5 definition: hbm / vmem / valu, each
+    achieved over peak, the top-level pair = the largest of the three; its instruction and byte counts come from `rocprofv3 --pmc`
+    passes the command runs on its own child processes in the same invocation, and agree with the committed counter file of the same
+    device code to a fraction of a per cent (the counts of a deterministic kernel)."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, bench, "--steps", "20", "--warmup", "4", "--trials", "3", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    roof = line["roofline"]
+    assert line["value"] > 1000 and line["frames_mismatched"] == 0 and line["unit"] == "Mrays/s"
+    fracs = {"hbm": roof["hbm"]["frac_measured"], "vmem": roof["vmem"]["frac"], "valu": roof["valu"]["frac"]}
+    assert all(0.0 < f < 1.0 for f in fracs.values()), fracs
+    assert roof["bound"] == max(fracs, key=fracs.get) and roof["frac"] == fracs[roof["bound"]]
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3 and roof["traffic"] > 0
+    assert roof["hbm"]["algorithmic_over_peak"] > 1.0 and roof["vmem"]["frac_scattered"] > roof["vmem"]["frac"] > roof["vmem"]["frac_at_one_record_peak"]
+    assert roof["counter_source"].startswith("rocprofv3 --pmc passes of this invocation"), roof["counter_source"]
+    agree = roof.get("archived_counters_agree")
+    if agree:       # the committed counter file is of this build: the same counts
+        assert all(abs(v - 1.0) < 0.01 for v in agree.values()), agree
+    assert not any(key.endswith("_busy") for key in roof if key != "busy_profiled")

@@ -716,7 +716,12 @@ def main():
                 pmc_note = f"{PMC_FILE} unreadable: {exc}"
             # the counts of THIS invocation where they can be had (the busy counters stay the archived run's: they are not rates)
             archived = pmc
-            if not args.no_live_counters and os.environ.get("SHRAY_BENCH_LIVE_COUNTERS", "1") != "0":
+            # (not when this process is itself being profiled -- profiles/run_profile.sh, the driver's own rocprofv3 run --: the
+            # profiler's environment would be inherited by the children)
+            profiled = any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+            if profiled:
+                pmc_note += "; live counters not taken: this process is running under a profiler"
+            if not profiled and not args.no_live_counters and os.environ.get("SHRAY_BENCH_LIVE_COUNTERS", "1") != "0":
                 tail = ["--width", str(WIDTH), "--height", str(HEIGHT), "--spp", str(SPP), "--material", str(args.material),
                         "--kernel", str(args.kernel), "--frames-per-launch", str(batch), "--frames-in-flight", str(lanes)] + \
                        (["--same-view"] if args.same_view else [])

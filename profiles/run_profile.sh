@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # before rocprofv3: its preloaded library initialises HIP ahead of bench.py
 cd /tmp
-BENCH="python3 $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline $EXTRA"
+BENCH="python3 $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-live-counters $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace pass exit $?"
 i=0

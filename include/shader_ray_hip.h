@@ -46,7 +46,8 @@ extern "C" {
 /* Bumped whenever a struct below changes layout or an entry point changes meaning; callers compare it with
  * shray_abi_version() before their first call.  1: round 1.  2: shray_tile_set grew tile_phase_count (20 bytes).
  * 3: round 3 (shray_scene_set_environment_storage, shray_render_counters_timed, shray_scene_dispatch_order,
- * shray_selftest_reciprocal, the shray_dist_* companion header). */
+ * shray_selftest_reciprocal, the shray_dist_* companion header).  4: round 4.  Round 5 only ADDED entry points
+ * (shray_bvh_build_device, shray_device_tree_*): no bump. */
 #define SHRAY_ABI_VERSION 4
 
 enum {

@@ -76,7 +76,9 @@ def test_device_build_of_the_benchmark_scenes(pkg, gpu, oracle_mod):
         device.close()
 
 
-@pytest.mark.parametrize("seed,kind", [(k, kind) for k, kind in enumerate(["uniform", "clusters", "sizes", "duplicates", "planes", "degenerate", "dense"] * 2)])
+# 14 soups in the suite; SHRAY_FUZZ_ROUNDS=n builds n times as many (seeds go on counting)
+@pytest.mark.parametrize("seed,kind", [(k, kind) for k, kind in enumerate(["uniform", "clusters", "sizes", "duplicates", "planes", "degenerate", "dense"]
+                                                                           * (2 * max(1, int(os.environ.get("SHRAY_FUZZ_ROUNDS", "1")))))])
 def test_device_build_of_random_soups(pkg, gpu, tmp_path, seed, kind):
     """Seeded random triangle soups (tests/test_gpu_fuzz.py's generator): duplicates (no split separates them: large leaves),
     axis-aligned sheets (boxes of zero thickness, barycentres on one plane), degenerate and huge triangles."""

@@ -118,15 +118,17 @@ def live_counters(argv_tail, batch, budget_s=100.0):
         out = tempfile.mkdtemp(prefix="shray_pmc_", dir="/tmp")
         cmd = [tool, "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                "--counter-child", "--steps", str(2 * ORBIT), "--warmup", "0"] + argv_tail
-        try:
-            run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8"), timeout=left,
+        child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8"),
                                  stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            _, err = child.communicate(timeout=left)
         except subprocess.TimeoutExpired:
+            _kill_tree(child.pid)          # the profiler AND the program it started
             shutil.rmtree(out, ignore_errors=True)
             return None, f"a counter pass ({group}) did not end within {left:.0f} s"
-        if run.returncode != 0:
+        if child.returncode != 0:
             shutil.rmtree(out, ignore_errors=True)
-            return None, f"a counter pass ({group}) left with code {run.returncode}: {run.stderr[-200:]}"
+            return None, f"a counter pass ({group}) left with code {child.returncode}: {(err or '')[-200:]}"
         rows = 0
         for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):

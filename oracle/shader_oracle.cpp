@@ -288,6 +288,12 @@ struct Ctx {
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
 uint32_t *g_visit_map = nullptr;
 
+// optional probe (profiles/quantised_record_probe.py; EXPERIMENTS R5.4): would a node record with its six planes quantised to steps of
+// `g_quant_step` (scene extent / 65536 for 16-bit planes) decide this visit?  A visit is UNDECIDED when the box grown by one step and
+// the box shrunk by one step answer fs:400's question differently.  {visits, undecided visits}, summed over the render's threads.
+float g_quant_step = 0.0f;
+std::atomic<unsigned long long> g_quant_visits{0}, g_quant_undecided{0};
+
 // optional per-pixel path planes (tests/pixel_classifier.py: where the frame is discontinuous): for spp == 1 plain frames,
 // path = bit 2i: bounce i hit a triangle, bit 2i + 1: that hit was lit (its shadow ray escaped; only when diffuse > 0),
 // bits 24-27: bounces that hit, bit 30: the iteration-cap marker; first_triangle = the primary ray's triangle or -1
@@ -477,6 +483,15 @@ void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surfac
         group gg = get_group(cx, g, offset);
         range r = range_intersect_box(gg.boxmin, gg.boxmax, theray, prevr);
         const uint64_t tests_before = cx.c.triangle_tests;
+        if (g_quant_step > 0.0f) {      // diagnostics only
+            const vec3 q = V(g_quant_step, g_quant_step, g_quant_step);
+            const range grown = range_intersect_box(gg.boxmin - q, gg.boxmax + q, theray, prevr);
+            const range shrunk = range_intersect_box(gg.boxmin + q, gg.boxmax - q, theray, prevr);
+            const bool a = (!range_is_empty(grown)) && (grown.t0 < hit.t), b = (!range_is_empty(shrunk)) && (shrunk.t0 < hit.t);
+            g_quant_visits.fetch_add(1, std::memory_order_relaxed);
+            if (a != b)
+                g_quant_undecided.fetch_add(1, std::memory_order_relaxed);
+        }
         if ((!range_is_empty(r)) && (r.t0 < hit.t)) {
             if (!gg.is_branch) {
                 for (float j = 0.0f; j < max_leaf_tests; j++) {
@@ -979,6 +994,18 @@ int shray_oracle_render(const shray_scene_desc *desc, const float *env_rgb, int 
         counters_out->samples = (uint64_t)width * (uint64_t)(row_end - row_begin) * (uint64_t)spp;
     }
     return 0;
+}
+
+// Diagnostics: the quantised-record probe (g_quant_step): step > 0 starts counting from zero, 0 stops; counts[2] = {visits, undecided}.
+void shray_oracle_quant_probe(float step, unsigned long long counts[2])
+{
+    if (counts) {
+        counts[0] = g_quant_visits.load();
+        counts[1] = g_quant_undecided.load();
+    }
+    g_quant_visits = 0;
+    g_quant_undecided = 0;
+    g_quant_step = step;
 }
 
 // Diagnostics: when set, shray_oracle_render also writes node visits per pixel (width*height uint32).

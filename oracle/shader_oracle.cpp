@@ -351,7 +351,9 @@ inline range range_intersect(range a, range b)                                  
 inline bool range_is_empty(range r) { return r.t0 >= r.t1; }                       // fs:193-196
 
 // fs:200-217 -- slab test with a true division per plane
-range range_intersect_box(vec3 boxmin, vec3 boxmax, const ray &theray, range prevr)
+// (always inlined into group_intersect's loop: with the diagnostics' cold callers below as further call sites the compiler stopped
+// inlining it there, and the oracle -- bench.py's cpu_baseline -- lost 40 % of its rate)
+__attribute__((always_inline)) inline range range_intersect_box(vec3 boxmin, vec3 boxmax, const ray &theray, range prevr)
 {
     float t0, t1;
     t0 = (boxmin.x - theray.P.x) / theray.D.x;
@@ -400,6 +402,44 @@ group get_group(Ctx &cx, float which, float hitmiss_offset)
     return g;
 }
 
+// Diagnostics (Ctx::decision_margin; tests/pixel_classifier.py), kept OUT of the timed loops: cold, never inlined -- the oracle is
+// also bench.py's cpu_baseline, and these bodies inside triangle_intersect / group_intersect cost it a quarter of its rate.
+__attribute__((noinline, cold)) void note_determinant(Ctx &cx, vec3 rayP, vec3 rayD, range r, float hit_t, vec3 v0, vec3 e0, vec3 e1,
+                                                      vec3 M, float det)
+{
+    // a triangle the ray WOULD hit, whose determinant lies at the rejection threshold of fs:312 (the small triangles of a
+    // 1M-triangle mesh seen at grazing incidence: |det| ~ 1e-7) -- taken by one fp32 evaluation, skipped by another
+    const float epsilon = 0.0000001f;
+    if (det == 0.0f)
+        return;
+    const float closeness = fabsf(fabsf(det) - epsilon) / epsilon;
+    if (closeness < 1e-2f) {
+        const float id = 1.0f / det;
+        const vec3 T0 = rayP - v0, Q0 = cross(T0, e0);
+        const float d0 = -dot(e1, Q0) * id, u0 = dot(T0, M) * id, w0 = dot(rayD, Q0) * id;
+        if (!(d0 > hit_t) && !(d0 < r.t0 || d0 > r.t1) && u0 >= 0.0f && w0 >= 0.0f && u0 + w0 <= 1.0f)
+            cx.decision_margin = gl_min(cx.decision_margin, closeness * 1e-3f);
+    }
+}
+
+__attribute__((noinline, cold)) void note_triangle_test(Ctx &cx, vec3 rayD, range r, float hit_t, vec3 T, vec3 Q, vec3 M, float inv_det, float d)
+{
+    // the distance of this test from each of its decisions
+    if (d > hit_t)
+        return;
+    const float uu = dot(T, M) * inv_det, vv = dot(rayD, Q) * inv_det;
+    const float inside = gl_min(gl_min(uu, vv), 1.0f - uu - vv);            // > 0 inside the triangle
+    const float scale = gl_max(fabsf(d), 1e-30f);
+    const float ends = gl_min(fabsf(d - r.t0), fabsf(d - r.t1)) / scale;    // relative distance from the range's ends
+    const bool in_range = !(d < r.t0 || d > r.t1);
+    if (in_range)
+        cx.decision_margin = gl_min(cx.decision_margin, fabsf(inside));
+    // (boxes are inflated by 1e-5 absolute, vectormath.h:189-195: a hit on a box face sits a few 1e-6 of d inside the range, safely
+    // -- d's own rounding is 1e-7 of it; the ends count twenty-fold, so that the classifier's 2e-5 means 1e-6 of d here)
+    if (inside >= 0.0f || fabsf(inside) < 1e-3f)
+        cx.decision_margin = gl_min(cx.decision_margin, 20.0f * ends);
+}
+
 // fs:297-346
 void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surface_hit &hit)
 {
@@ -414,18 +454,8 @@ void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surfac
     const vec3 M = cross(e1, theray.D);
     const float det = dot(e0, M);
     const float epsilon = 0.0000001f;
-    if (cx.track_decisions && det != 0.0f) {
-        // diagnostics only: a triangle the ray WOULD hit, whose determinant lies at the rejection threshold of fs:312 (the small
-        // triangles of a 1M-triangle mesh seen at grazing incidence: |det| ~ 1e-7) -- taken by one fp32 evaluation, skipped by another
-        const float closeness = fabsf(fabsf(det) - epsilon) / epsilon;
-        if (closeness < 1e-2f) {
-            const float id = 1.0f / det;
-            const vec3 T0 = theray.P - v0, Q0 = cross(T0, e0);
-            const float d0 = -dot(e1, Q0) * id, u0 = dot(T0, M) * id, w0 = dot(theray.D, Q0) * id;
-            if (!(d0 > hit.t) && !(d0 < r.t0 || d0 > r.t1) && u0 >= 0.0f && w0 >= 0.0f && u0 + w0 <= 1.0f)
-                cx.decision_margin = gl_min(cx.decision_margin, closeness * 1e-3f);
-        }
-    }
+    if (__builtin_expect(cx.track_decisions, 0))
+        note_determinant(cx, theray.P, theray.D, r, hit.t, v0, e0, e1, M, det);
     if (det > -epsilon && det < epsilon)
         return;
     const float inv_det = 1.0f / det;
@@ -433,20 +463,8 @@ void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surfac
     const vec3 T = theray.P - v0;
     const vec3 Q = cross(T, e0);
     const float d = -dot(e1, Q) * inv_det;
-    if (cx.track_decisions && !(d > hit.t)) {
-        // diagnostics only (never in a timed or compared render): the distance of this test from each of its decisions
-        const float uu = dot(T, M) * inv_det, vv = dot(theray.D, Q) * inv_det;
-        const float inside = gl_min(gl_min(uu, vv), 1.0f - uu - vv);            // > 0 inside the triangle
-        const float scale = gl_max(fabsf(d), 1e-30f);
-        const float ends = gl_min(fabsf(d - r.t0), fabsf(d - r.t1)) / scale;    // relative distance from the range's ends
-        const bool in_range = !(d < r.t0 || d > r.t1);
-        if (in_range)
-            cx.decision_margin = gl_min(cx.decision_margin, fabsf(inside));
-        // (boxes are inflated by 1e-5 absolute, vectormath.h:189-195: a hit on a box face sits a few 1e-6 of d inside the range, safely
-        // -- d's own rounding is 1e-7 of it; the ends count twenty-fold, so that the classifier's 2e-5 means 1e-6 of d here)
-        if (inside >= 0.0f || fabsf(inside) < 1e-3f)
-            cx.decision_margin = gl_min(cx.decision_margin, 20.0f * ends);
-    }
+    if (__builtin_expect(cx.track_decisions, 0))
+        note_triangle_test(cx, theray.D, r, hit.t, T, Q, M, inv_det, d);
     if (d > hit.t)
         return;
     if (d < r.t0 || d > r.t1)
@@ -462,6 +480,20 @@ void triangle_intersect(Ctx &cx, float which, const ray &theray, range r, surfac
     hit.uvw.x = 1.0f - u - v;
     hit.uvw.y = u;
     hit.uvw.z = v;
+}
+
+__attribute__((noinline, cold)) void note_quantised_visit(vec3 boxmin, vec3 boxmax, vec3 rayP, vec3 rayD, range prevr, float hit_t)
+{
+    ray theray{};
+    theray.P = rayP;
+    theray.D = rayD;
+    const vec3 q = V(g_quant_step, g_quant_step, g_quant_step);
+    const range grown = range_intersect_box(boxmin - q, boxmax + q, theray, prevr);
+    const range shrunk = range_intersect_box(boxmin + q, boxmax - q, theray, prevr);
+    const bool a = (!range_is_empty(grown)) && (grown.t0 < hit_t), b = (!range_is_empty(shrunk)) && (shrunk.t0 < hit_t);
+    g_quant_visits.fetch_add(1, std::memory_order_relaxed);
+    if (a != b)
+        g_quant_undecided.fetch_add(1, std::memory_order_relaxed);
 }
 
 // fs:386-443, CONSTANT_LENGTH_LOOPS branch
@@ -483,15 +515,8 @@ void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surfac
         group gg = get_group(cx, g, offset);
         range r = range_intersect_box(gg.boxmin, gg.boxmax, theray, prevr);
         const uint64_t tests_before = cx.c.triangle_tests;
-        if (g_quant_step > 0.0f) {      // diagnostics only
-            const vec3 q = V(g_quant_step, g_quant_step, g_quant_step);
-            const range grown = range_intersect_box(gg.boxmin - q, gg.boxmax + q, theray, prevr);
-            const range shrunk = range_intersect_box(gg.boxmin + q, gg.boxmax - q, theray, prevr);
-            const bool a = (!range_is_empty(grown)) && (grown.t0 < hit.t), b = (!range_is_empty(shrunk)) && (shrunk.t0 < hit.t);
-            g_quant_visits.fetch_add(1, std::memory_order_relaxed);
-            if (a != b)
-                g_quant_undecided.fetch_add(1, std::memory_order_relaxed);
-        }
+        if (__builtin_expect(g_quant_step > 0.0f, 0))
+            note_quantised_visit(gg.boxmin, gg.boxmax, theray.P, theray.D, prevr, hit.t);
         if ((!range_is_empty(r)) && (r.t0 < hit.t)) {
             if (!gg.is_branch) {
                 for (float j = 0.0f; j < max_leaf_tests; j++) {

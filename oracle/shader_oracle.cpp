@@ -288,7 +288,7 @@ struct Ctx {
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
 uint32_t *g_visit_map = nullptr;
 
-// optional probe (profiles/quantised_record_probe.py; EXPERIMENTS R5.4): would a node record with its six planes quantised to steps of
+// optional probe (tests/quantised_record_probe.py; EXPERIMENTS R5.4): would a node record with its six planes quantised to steps of
 // `g_quant_step` (scene extent / 65536 for 16-bit planes) decide this visit?  A visit is UNDECIDED when the box grown by one step and
 // the box shrunk by one step answer fs:400's question differently.  {visits, undecided visits}, summed over the render's threads.
 float g_quant_step = 0.0f;

@@ -2,12 +2,12 @@
 """EXPERIMENTS R5.4: how often would a 16-byte node record with 16-bit quantised planes leave a visit undecided?  Runs the CPU
 oracle (no GPU) on the benchmark frame with its probe on: a visit counts as undecided when the box grown by one quantisation step
 and the box shrunk by one step answer the visit's question differently.
-    python profiles/quantised_record_probe.py [width height]"""
+    python tests/quantised_record_probe.py [width height]"""
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/: the oracle is test infrastructure)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from __graft_entry__ import load_package  # noqa: E402
 import oracle  # noqa: E402

@@ -3,7 +3,7 @@
 is: this container).  raytracer.vs + raytracer.es.fs, unmodified, on Mesa's llvmpipe (oracle/glsl_ref/glsl_ref.cpp);
 prints per configuration how many pixels of the 1920 x 1080 frame agree within 1e-4 relative and where the rest sit.
 
-    python profiles/reference_shader_agreement.py > profiles/history/r03/reference_shader_agreement.txt
+    python tests/reference_shader_agreement.py > profiles/history/r03/reference_shader_agreement.txt
 """
 import os
 import sys

@@ -727,7 +727,10 @@ def main():
                 tail = ["--width", str(WIDTH), "--height", str(HEIGHT), "--spp", str(SPP), "--material", str(args.material),
                         "--kernel", str(args.kernel), "--frames-per-launch", str(batch), "--frames-in-flight", str(lanes)] + \
                        (["--same-view"] if args.same_view else [])
-                live, live_note = live_counters(tail, batch)
+                try:
+                    live, live_note = live_counters(tail, batch)
+                except Exception as exc:   # noqa: BLE001  (a measurement aid must not cost the run its line)
+                    live, live_note = None, f"live_counters raised {exc!r}"
                 if live:
                     if archived and archived["build_hash"] == kernel_source_hash():
                         for key in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac_profiled", "wait_frac", "serialized_launch_ms",

@@ -223,24 +223,52 @@ def launch_ranks(n, budget):
             sock.bind(("127.0.0.1", 0))
             return sock.getsockname()[1]
 
+    import threading
+
     deadline = time.time() + budget + float(os.environ.get("SHRAY_BENCH_PARENT_SLACK", "120"))   # (slack: a fresh box's first `import torch`)
     for attempt in range(2):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         log("bench.py: no WORLD_SIZE in the environment, launching", " ".join(cmd), f"(budget {budget:.0f} s)")
-        # the ranks' own watchdogs (arm_watchdog) fire first and say where they were; this budget is the backstop behind them
+        # the ranks' own watchdogs (arm_watchdog) fire first and say where they were; this budget is the backstop behind them.
+        # The child's stdout comes through a pipe: the parent relays it line by line and KNOWS whether a record went out, so
+        # that exactly one does (a rank other than 0 whose timer fires first makes the launcher end rank 0
+        # before rank 0 has spoken; a rank 0 that has printed its result and then hangs in the shutdown barrier must not add
+        # a second record).
         started = time.time()
-        child = subprocess.Popen(cmd, start_new_session=True)
+        child = subprocess.Popen(cmd, start_new_session=True, stdout=subprocess.PIPE, text=True, bufsize=1)
+        records = []
+
+        def relay(pipe=child.stdout, seen=records):
+            for line in pipe:
+                if line.lstrip().startswith("{"):
+                    if seen:
+                        log("bench.py: a second record from the ranks was dropped:", line.strip()[:200])
+                        continue
+                    seen.append(line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+
+        reader = threading.Thread(target=relay, daemon=True)
+        reader.start()
         try:
             rc = child.wait(timeout=max(1.0, deadline - time.time()) if budget > 0 else None)
         except subprocess.TimeoutExpired:
             log(f"bench.py: the ranks did not finish within {budget:.0f} s: killing them")
             _kill_tree(child.pid)
+            reader.join(timeout=5.0)
+            if records:      # the result went out and the ranks then hung in their shutdown: the run's line stands
+                return 0
             print(timeout_line(n, budget, "parent: the child process group was killed"), flush=True)
             return 124
+        reader.join(timeout=5.0)
         # a launcher that died at once (its rendezvous port taken after all) gets one more try on another port; a rank's own
         # failure takes longer than that (it has imported torch) and is final
         if rc == 0 or attempt == 1 or time.time() - started > 8.0:
+            if rc != 0 and not records and budget > 0 and time.time() - started >= budget - 1.0:
+                # a rank's watchdog fired and the launcher ended the others before rank 0 printed the record
+                print(timeout_line(n, budget, f"parent: a rank's watchdog ended the run (launcher exit code {rc})"), flush=True)
+                return 124
             return rc
         log(f"bench.py: the launcher left with code {rc} after {time.time() - started:.1f} s: once more on another port")
     return rc
@@ -263,7 +291,8 @@ def arm_watchdog(rank, n, budget):
         os._exit(124)
 
     if budget > 0:
-        t = threading.Timer(budget, fire)
+        # rank 0 speaks first: the others fire three seconds later (their os._exit makes the launcher end rank 0)
+        t = threading.Timer(budget if rank == 0 else budget + 3.0, fire)
         t.daemon = True
         t.start()
         _watchdog["timer"] = t
@@ -888,6 +917,11 @@ def main():
         if alt is not None:
             result["alt_root_mode"] = alt
         print(json.dumps(result), flush=True)
+        # the record is out: from here on the watchdog must not add a second one (a hang in the shutdown barrier is the
+        # launcher's or the parent's to end)
+        if _watchdog["timer"] is not None:
+            _watchdog["timer"].cancel()
+            _watchdog["timer"] = None
     if distributed:
         stage("shutdown")
         dist.barrier()

@@ -16,6 +16,7 @@
 #pragma once
 
 #include "wave_traversal.h"
+#include "visit_asm.h"
 
 namespace shray {
 
@@ -108,8 +109,16 @@ struct StackTraversal {
             if (PAIR) {
                 inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);
-            } else
-                inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
+            } else {
+#if SHRAY_ASM_VISIT && !defined(SHRAY_DIAGNOSTICS)
+                // the timed instances: the node stage as one hand-scheduled statement (visit_asm.h); the counting twins keep
+                // the compiler's form (their tallies, and the cap in front of every visit)
+                if (!COUNT)
+                    inner_stage_scheduled<BLOCK>(sc, fr, t, state, stack, rc, keep);
+                else
+#endif
+                    inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
+            }
 #if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif

@@ -218,6 +218,8 @@ bool adopt_tree(const world_ptr &w, int node_count, const int *negative, const i
 {
     if (!w || !w->triangles || w->root || node_count <= 0 || triangle_count != (int)w->triangles->triangles.size())
         return false;
+    if (!negative || !positive || !box || !direction || !start || !triangles || !triangle_order)
+        return false;
     triangle_set &mesh = *w->triangles;
     // every triangle once, every leaf range inside the array, children after their parent (pre-order)
     std::vector<char> seen((size_t)triangle_count, 0);
@@ -237,6 +239,22 @@ bool adopt_tree(const world_ptr &w, int node_count, const int *negative, const i
     }
     if (covered != triangle_count)
         return false;
+    // ... and the arrays ARE a pre-order binary tree: a branch's positive child starts right behind its negative child's
+    // subtree, and the root's subtree is the whole array -- so that every node has exactly one parent (a node
+    // named by two parents would be deleted twice).  Sizes from the back: children come after their parent.
+    {
+        std::vector<int> size((size_t)node_count, 1);
+        for (int g = node_count - 1; g >= 0; g--) {
+            if (negative[g] < 0)
+                continue;
+            const int n = negative[g], p = positive[g];
+            if (p != n + size[(size_t)n])
+                return false;
+            size[(size_t)g] = 1 + size[(size_t)n] + size[(size_t)p];
+        }
+        if (size[0] != node_count)
+            return false;
+    }
     std::vector<indexed_triangle> ordered;
     ordered.reserve((size_t)triangle_count);
     for (int k = 0; k < triangle_count; k++)

@@ -266,6 +266,17 @@ def test_load_triangles_and_adopt_tree(pkg):
     tree.node_negative[branch] = saved + 1
     assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.0) == -1
     tree.node_negative[branch] = saved
+    # refused: arrays that pass every local check (negative == g + 1 < positive < node_count, leaves in triangle order) and are
+    # still no tree -- a branch's positive child must start right behind its negative child's subtree; moved by one, a node would
+    # have two parents (and be deleted twice)
+    positive = np.ctypeslib.as_array(tree.node_positive, shape=(n,)).copy()
+    for branch in np.nonzero(negative >= 0)[0].tolist():
+        was = int(positive[branch])
+        for moved in (was - 1, was + 1):
+            if int(negative[branch]) < moved < n:
+                tree.node_positive[branch] = moved
+                assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.0) == -1, (branch, moved)
+        tree.node_positive[branch] = was
     # adopted: the same flattened arrays and statistics as the world make_bvh built
     assert lib.shray_host_adopt_tree(handle, C.byref(tree), order_p, 0.125) == 0
     info = N.HostWorldInfo()

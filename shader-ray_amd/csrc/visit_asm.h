@@ -21,8 +21,8 @@
 //     operands (no moves into lanes' registers);
 //   * the pop is `top != stack` as v_cmpx (the lanes whose stacks are empty drop out of EXEC and of the walking mask in that one
 //     instruction), the push a write under the branch lanes' mask.
-// Per turn with lanes on both the descend and the pop path (profiles/isa_loops.py visit_asm): 32 vector (2 of them fetches, 2 LDS) and
-// 16 scalar instructions (3 of them waits / a two-state nop), + 7 / 4 when a lane parks.
+// Per turn with lanes on both the descend and the pop path: 31 vector (2 of them fetches, 2 LDS) and
+// 16 scalar instructions (3 of them waits / a two-state nop), + 8 / 4 when a lane parks.
 // Same visits, same order, same counts (`left`): frames and tallies bit-identical (the GPU parity suite runs through this stage).
 #pragma once
 
@@ -36,7 +36,7 @@ namespace shray {
 
 // One turn: every lane in EXEC (= the walking mask, not empty) visits its node.  Registers: v[2:5] v[6:9] the record
 // { entry.x, entry.y, exit.x, exit.y } { entry.z, exit.z, a, b } (DeviceNode, packed_layout.h), then in place the six differences,
-// the six products; v2 = r0~, v4 = r1~ (not clamped to 1e8), v3 = below, then d.  s[64:71]: a record fetched through the scalar cache.
+// the six products; v2 = r0~, v3 = below, then d; v4 = r1~ on the leaf path.  s[64:71]: a record fetched through the scalar cache.
 #define SHRAY_VISIT_TURN(K)                                                                                                      \
     "s_waitcnt lgkmcnt(0)\n\t"                              /* the node the last turn took off the stack */                       \
     "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"              /* node_address(): (name << 3) + octant */                            \
@@ -76,8 +76,8 @@ namespace shray {
     "v_mul_f32_e32 v7, v7, %[Yz]\n\t"                                                                                           \
     "v_max3_f32 v2, v2, v3, v6\n\t"                                                                                             \
     "v_max_i32_e32 v2, 0, v2\n\t"                           /* r0~ = max(0, ...), and never -0 */                                 \
-    "v_min3_f32 v4, v4, v5, v7\n\t"                         /* r1~, not yet clamped to 1e8 (hit.t is below 1e8) */               \
-    "v_min_f32_e32 v3, v4, %[HT]\n\t"                       /* below = min(r1~, hit.t) */                                         \
+    "v_min3_f32 v3, v4, v5, %[HT]\n\t"                      /* below = min(r1~, hit.t) in two instructions: hit.t takes the */    \
+    "v_min_f32_e32 v3, v3, v7\n\t"                          /* place of the third product (r1~ itself: the leaf path)       */    \
     "v_sub_i32 v3, v3, v2 clamp\n\t"                        /* d */                                                               \
     "v_cmp_gt_i32_e64 %[sE], v3, 16\n\t"                    /* entered */                                                         \
     "v_cmp_gt_i32_e32 vcc, -16, v3\n\t"                     /* not entered */                                                     \
@@ -86,12 +86,12 @@ namespace shray {
     "s_andn2_b64 %[sT], exec, %[sT]\n\t"                                                                                        \
     "s_cbranch_scc1 vslow_%=\n\t"                           /* some lane is not: the compiler's visit makes this turn */         \
     "v_cmp_gt_i32_e32 vcc, 0, v9\n\t"                       /* b's flag: a leaf's record */                                       \
-    "s_andn2_b64 %[sT], %[sE], vcc\n\t"                     /* lanes that enter a branch */                                       \
     "s_and_b64 %[sL], %[sE], vcc\n\t"                       /* lanes that enter a leaf */                                         \
     "s_cbranch_scc0 vb" #K "_%=\n\t"                                                                                            \
     "s_mov_b64 exec, %[sL]\n\t"                                                                                                 \
     "v_cmp_eq_u32_e32 vcc, 0x80000000, v9\n\t"              /* a leaf without triangles: the compiler's visit */                 \
     "s_cbranch_vccnz vslow_%=\n\t"                                                                                              \
+    "v_min3_f32 v4, v4, v5, v7\n\t"                         /* r1~ */                                                             \
     "v_min_f32_e32 v4, 0x4cbebc20, v4\n\t"                  /* the range's end is at most 1e8 (fs:392) */                         \
     "v_mul_f32_e32 %[LR1], 0x3f800008, v4\n\t"              /* parked: an upper bound of r1, */                                   \
     "v_mul_f32_e32 %[LR0], 0x3f7ffff0, v2\n\t"              /* a lower bound of r0, */                                            \
@@ -99,15 +99,18 @@ namespace shray {
     "v_mov_b32_e32 %[LC], v9\n\t"                           /* the count word as it is (parked_count) */                          \
     "s_or_b64 %[sP], %[sP], %[sL]\n"                                                                                            \
     "vb" #K "_%=:\n\t"                                                                                                          \
+    "s_andn2_b64 exec, %[sW], %[sE]\n\t"                    /* not entered: the next node comes off the stack ... */             \
+    "s_cbranch_scc0 vp" #K "_%=\n\t"                        /* (nobody: no LDS read to wait for at the next turn) */             \
+    "v_cmpx_ne_u32_e32 %[T], %[B]\n\t"                      /* ... unless it is empty: those lanes have ended */                  \
+    "v_add_u32_e32 %[T], %[down], %[T]\n\t"                                                                                     \
+    "ds_read_b32 %[N], %[T]\n"                                                                                                  \
+    "vp" #K "_%=:\n\t"                                                                                                          \
+    "s_andn2_b64 %[sT], %[sE], %[sL]\n\t"                   /* lanes that enter a branch */                                       \
+    "s_or_b64 %[sW], %[sT], exec\n\t"                       /* still walking: they, and the lanes that took a node off */        \
     "s_mov_b64 exec, %[sT]\n\t"                             /* descend: push the other child, go to the first */                  \
     "ds_write_b32 %[T], v9\n\t"                                                                                                 \
     "v_add_u32_e32 %[T], %[up], %[T]\n\t"                                                                                       \
     "v_mov_b32_e32 %[N], v8\n\t"                                                                                                \
-    "s_andn2_b64 exec, %[sW], %[sE]\n\t"                    /* not entered: the next node comes off the stack ... */             \
-    "v_cmpx_ne_u32_e32 %[T], %[B]\n\t"                      /* ... unless it is empty: those lanes have ended */                  \
-    "v_add_u32_e32 %[T], %[down], %[T]\n\t"                                                                                     \
-    "ds_read_b32 %[N], %[T]\n\t"                                                                                                \
-    "s_or_b64 %[sW], %[sT], exec\n\t"                       /* still walking */                                                   \
     "s_mov_b64 exec, %[sW]\n\t"                                                                                                 \
     "s_cbranch_execz vg_%=\n\t"
 
@@ -200,6 +203,7 @@ __device__ __forceinline__ void inner_stage_scheduled(const SceneView &sc, const
               [up] "i"((unsigned int)(4 * BLOCK)), [down] "i"((unsigned int)(-4 * BLOCK))
             : "vcc", "scc", "memory", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71");
         t.top = (uint32_t *)top;
+        reason = (uint32_t)__builtin_amdgcn_readfirstlane((int)reason);   // (an asm statement's results count as divergent: say it is not)
         if (reason == VISIT_STAGE_OVER)
             return;
         if (reason == VISIT_CAP) {

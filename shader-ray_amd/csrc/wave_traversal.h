@@ -623,6 +623,24 @@ __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t,
     } while (wave_ballot(j < mine));
 }
 
+// The same loop for the timed instances as one hand-scheduled statement (leaf_asm.h, included at the end of this file); the
+// counting twins, the pair traversal (exact parked ranges) and the diagnostic build keep the compiler's form.
+#ifndef SHRAY_ASM_LEAF
+#define SHRAY_ASM_LEAF 1
+#endif
+__device__ __forceinline__ void leaf_loop_scheduled(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc);
+template <bool COUNT, bool BOUNDS>
+__device__ __forceinline__ void leaf_loop_timed_or_counted(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
+{
+#if SHRAY_ASM_LEAF && !defined(SHRAY_DIAGNOSTICS)
+    if (!COUNT && BOUNDS) {
+        leaf_loop_scheduled(sc, t, state, rc);
+        return;
+    }
+#endif
+    leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+}
+
 // Leaf cache (round 5).  The lanes of a wave that are parked TOGETHER mostly sit in the same few leaves: the rays of an 8x8
 // tile reach a leaf side by side.  Stages with more than 32 parked lanes, the plain loop's share of the throughput form:
 // ONE distinct leaf in 51 % of them, two in 31 %, three in 11 %, at most four in 96 % (1M-triangle scene: 15 / 28 / 25 %,
@@ -764,7 +782,7 @@ __device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView 
     if (CACHE && t.leaf_cap <= kCacheTriangles)     // (uniform)
         leaf_loop_cached<COUNT, !PAIR>(sc, t, state, rc, reinterpret_cast<char *>(ids) + kIdsBytes SHRAY_DIAG_ARG_FWD);
     else
-        leaf_loop<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+        leaf_loop_timed_or_counted<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
 }
 
@@ -1007,7 +1025,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
         } else if (COUNT && !tallied)
             leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
         else
-            leaf_loop<false, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
+            leaf_loop_timed_or_counted<false, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
     } else if (state == LT_LEAF && won != 0xffffffffu) {
         // the parked lane takes its group's winner (its number in the leaf)
         t.hit.which = (float)(t.leaf_first + won);
@@ -1176,3 +1194,5 @@ __device__ __forceinline__ void retest_stage(const SceneView &sc, LaneTraversal 
 }
 
 }   // namespace shray
+
+#include "leaf_asm.h"

@@ -11,7 +11,9 @@ __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE
                                                                                                float4 *out, size_t frame_stride, int stack_levels,
                                                                                                int frame_count_arg)
 {
-    stack_batch_body<ONE_SAMPLE, METAL, DEAL, 0, false>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+    // (one sample, zero diffuse, dealing: the six-wave instance, SHRAY_MIN_WAVES_DEALT)
+    stack_batch_body<ONE_SAMPLE, METAL, DEAL, 0, false, false, ONE_SAMPLE && METAL && DEAL && SHRAY_MIN_WAVES_DEALT <= 6>(sc, frames, out, frame_stride, stack_levels,
+                                                                                                                   frame_count_arg, nullptr);
 }
 
 // Several spp == 1 zero-diffuse frames per launch (the throughput form): the dealt leaf stage at SEVEN waves per SIMD
@@ -33,7 +35,8 @@ __global__ void __launch_bounds__(kBatchBlock, DENSE ? SHRAY_MIN_WAVES_DEALT_DEN
     trace_stack_batch_ordered_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride, int stack_levels,
                                      int frame_count_arg)
 {
-    stack_batch_body<ONE_SAMPLE, true, DEAL, 0, false, true>(sc, frames, out, frame_stride, stack_levels, frame_count_arg, nullptr);
+    stack_batch_body<ONE_SAMPLE, true, DEAL, 0, false, true, ONE_SAMPLE && DEAL && !DENSE && SHRAY_MIN_WAVES_DEALT <= 6>(sc, frames, out, frame_stride, stack_levels,
+                                                                                                                 frame_count_arg, nullptr);
 }
 
 void launch_stack_batch_timed(const SceneView &sc, const BatchLaunch &b)

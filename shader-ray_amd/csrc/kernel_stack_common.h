@@ -98,10 +98,10 @@ inline size_t stack_lds_bytes(int stack_levels, int block = kBlock, bool cache =
     return (size_t)block * (size_t)stack_levels * sizeof(uint32_t) + (size_t)(block / 64) * (kIdsBytes + (cache ? kCacheBytes : 0u) + park + SHRAY_LDS_PAD);
 }
 
-template <bool DEAL, int BLOCK = kBlock, bool PAIR = false, bool CACHE = false>
-__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR, CACHE> make_traversal(uint32_t *lds, int stack_levels)
+template <bool DEAL, int BLOCK = kBlock, bool PAIR = false, bool CACHE = false, bool ROOMY = false>
+__device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR, CACHE, ROOMY> make_traversal(uint32_t *lds, int stack_levels)
 {
-    StackTraversal<BLOCK, DEAL, PAIR, CACHE> trav;
+    StackTraversal<BLOCK, DEAL, PAIR, CACHE, ROOMY> trav;
     trav.stack = lds + threadIdx.x;
     trav.ids = reinterpret_cast<uint8_t *>(lds + (size_t)stack_levels * BLOCK) + (threadIdx.x >> 6) * (kIdsBytes + (CACHE ? kCacheBytes : 0u));
     return trav;
@@ -113,13 +113,14 @@ __device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR, CACHE> make_travers
 // TALLY: 0 = the timed kernels; 1 = the same form with per-ray work tallies (what the timed form does); 2 = tallies of
 // the reference's walk (one lane per pixel, every shadow ray to its end) -- the counting twin of the pair traversal.
 // PAIR: both children of a node per turn (wave_traversal.h).  ORDERED: the launch reads a dispatch order (capi.hip).
-template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR, bool ORDERED = false>
+// ROOMY: the kernel is compiled for six waves per SIMD (stack_traversal.h).
+template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR, bool ORDERED = false, bool ROOMY = false>
 __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,
                                                  int stack_levels, int frame_count_arg, DeviceCounters *counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR, caches_leaves(PAIR)>;
-    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR, caches_leaves(PAIR)>(lds_stack, stack_levels);
+    using Traversal = StackTraversal<kBatchBlock, DEAL, PAIR, caches_leaves(PAIR), ROOMY>;
+    Traversal trav = make_traversal<DEAL, kBatchBlock, PAIR, caches_leaves(PAIR), ROOMY>(lds_stack, stack_levels);
     // the frames of a launch share grid.x, frame index fastest after the (XCD, wave-of-patch) bits: the same patch
     // of every frame starts at about the same time on the same XCD, so the last frame's long-running waves do not
     // start when the launch is half over (what a lone launch, or the last of a run, then waits for)

@@ -42,7 +42,8 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 // DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
 // PAIR: both children of a node per turn (wave_traversal.h: inner_stage_pair); convergent form only
 // CACHE: the sequential leaf loop reads a stage's distinct leaves from the wave's LDS slab (wave_traversal.h: leaf cache; `ids` is followed by it)
-template <int BLOCK, bool DEAL = true, bool PAIR = false, bool CACHE = false>
+// ROOMY: an instance compiled for six waves per SIMD: the dealt stage's rounds are hand-scheduled too (wave_traversal.h: dealt_search)
+template <int BLOCK, bool DEAL = true, bool PAIR = false, bool CACHE = false, bool ROOMY = false>
 struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
@@ -123,7 +124,7 @@ struct StackTraversal {
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
             if (DEAL && CONVERGED)
-                leaf_stage_dealt<COUNT, BLOCK, PAIR, CACHE>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
+                leaf_stage_dealt<COUNT, BLOCK, PAIR, CACHE, ROOMY>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             else
                 leaf_stage<COUNT, BLOCK, PAIR, CACHE>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             if (ANY_HIT && state != LT_ENDED && t.hit.t < kFar)

@@ -629,6 +629,8 @@ __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t,
 #define SHRAY_ASM_LEAF 1
 #endif
 __device__ __forceinline__ void leaf_loop_scheduled(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc);
+__device__ __forceinline__ bool dealt_rounds_scheduled(const SceneView &sc, const LaneTraversal &t, int source, uint32_t end, uint32_t G,
+                                                       uint32_t tri, uint32_t where, float &best_d, float &best_u, float &best_w, uint32_t &best);
 template <bool COUNT, bool BOUNDS>
 __device__ __forceinline__ void leaf_loop_timed_or_counted(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
 {
@@ -851,7 +853,11 @@ __device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r
 // lane number)
 // CACHED: the stage's first kCacheSlots distinct leaves come through the wave's leaf cache (`ids` is followed by it); the
 // workers of a ray whose leaf got no slot fetch their triangles themselves, as before.
-template <bool COUNT, bool BOUNDS, bool CACHED>
+// ROOMY: the instance is compiled for six waves per SIMD (80 registers): its rounds run as one hand-scheduled statement
+// (leaf_asm.h: dealt_rounds_scheduled).  Measured (profiles/EXPERIMENTS.md R6.3): a lone frame 0.356 -> 0.349 ms there, but the
+// seven- and eight-wave instances lose 2 % with it (throughput form 11,951 -> 11,743 Mrays/s, config 4 2.18 -> 2.21 ms): they keep
+// the compiler's rounds.
+template <bool COUNT, bool BOUNDS, bool CACHED, bool ROOMY = false>
 __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTraversal &t, int state, RayCounters &rc, uint8_t *ids,
                                              unsigned long long parked, int K, float &wd, float &wu, float &ww,
                                              uint32_t &won SHRAY_DIAG_PARAM)
@@ -875,10 +881,22 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
     const int group = lane >> log_g, sub = lane & (G - 1);
     const bool worker = group < K;
     const int src = worker ? (int)ids[group] : lane;    // same wave, LDS operations complete in order
+    // the timed instances run their rounds as one hand-scheduled statement (leaf_asm.h: dealt_rounds_scheduled), which also
+    // pulls the ray -- behind the first round's fetches, so that the pulls' LDS round trips and the fetch overlap
+#if SHRAY_ASM_LEAF && !defined(SHRAY_DIAGNOSTICS)
+    constexpr bool SCHEDULED = ROOMY && !COUNT && BOUNDS && !CACHED;
+#else
+    constexpr bool SCHEDULED = false;
+#endif
     // the parked ray, as its workers see it
-    const V3 P = mk(lane_pull(src, t.P.x), lane_pull(src, t.P.y), lane_pull(src, t.P.z));
-    const V3 D = mk(lane_pull(src, t.D.x), lane_pull(src, t.D.y), lane_pull(src, t.D.z));
-    const float r0 = lane_pull(src, t.leaf_r0), r1 = lane_pull(src, t.leaf_r1);
+    V3 P = mk(0, 0, 0), D = mk(0, 0, 0);
+    float r0 = 0.0f, r1 = 0.0f;
+    if (!SCHEDULED) {
+        P = mk(lane_pull(src, t.P.x), lane_pull(src, t.P.y), lane_pull(src, t.P.z));
+        D = mk(lane_pull(src, t.D.x), lane_pull(src, t.D.y), lane_pull(src, t.D.z));
+        r0 = lane_pull(src, t.leaf_r0);
+        r1 = lane_pull(src, t.leaf_r1);
+    }
     // worker i of a group walks triangles i, i + G, ... < count of its ray's leaf; the winner is kept as that number
     const uint32_t first = (uint32_t)lane_pull(src, (int)t.leaf_first);
     // (every pull is a statement of its own, executed by all 64 lanes: ds_bpermute returns 0 for a source lane that
@@ -898,10 +916,18 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         if (cached)
             leaf_cache_wait(where);
     }
-    float best_d = lane_pull(src, t.hit.t), best_u = 0.0f, best_w = 0.0f;
+    float best_d = 0.0f, best_u = 0.0f, best_w = 0.0f;
+    if (!SCHEDULED)
+        best_d = lane_pull(src, t.hit.t);
     uint32_t best = 0xffffffffu;    // no candidate accepted
     uint32_t unordered_flag = 0u;   // accepted a candidate whose d is NaN (see above); set by the tied form below
     SHRAY_DIAG_COUNT(6);
+    if (SCHEDULED) {
+        if (dealt_rounds_scheduled(sc, t, src << 2, end, (uint32_t)G, (uint32_t)sub, where, best_d, best_u, best_w, best)) {
+            asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");
+            return true;
+        }
+    } else {
     // bottom-tested, like leaf_stage's loop: group 0's first worker always has a triangle
     uint32_t tri = (uint32_t)sub;
     do {
@@ -942,6 +968,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
         asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
         return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
     }
+    }
     // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
     for (int step = 1; step < G; step <<= 1) {
         const int other = lane ^ step;
@@ -967,7 +994,7 @@ __device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTrav
 // unordered fallback in the timed instances, and one end (leaf_finish) serves every path: each inlined copy is another
 // 150 instructions and another set of register copies where its results meet the other paths'.
 // CACHE: `ids` is followed by the wave's leaf cache; the crowded stage's sequential loop reads its triangles from there
-template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false>
+template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false, bool ROOMY = false>
 __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
                                                  uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
 {
@@ -1012,7 +1039,7 @@ __device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const Fram
     uint32_t won = 0xffffffffu;
     bool plain = K > SHRAY_DEAL_MAX_PARKED, tallied = false;
     if (!plain) {
-        plain = dealt_search<COUNT, BOUNDS, CACHE && SHRAY_LEAF_CACHE_DEALT != 0>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
+        plain = dealt_search<COUNT, BOUNDS, CACHE && SHRAY_LEAF_CACHE_DEALT != 0, ROOMY>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
         tallied = true;
     }
     if (plain) {

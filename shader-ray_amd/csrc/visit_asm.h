@@ -18,7 +18,8 @@
 //     Undecided lanes (about one visit in 10^5), lanes that divide, and empty leaves leave the statement: the turn is made by the
 //     compiler's form of the visit (lane_visit_loaded), which holds the exact quotients;
 //   * a record every walking lane is at comes through the scalar cache as before, and its planes are the subtractions' scalar
-//     operands (no moves into lanes' registers);
+//     operands (no moves into lanes' registers; four v_mov_b64 and the vector path's own subtractions measure 1 % slower, and
+//     without the scalar path at all the throughput form loses 10 %: profiles/EXPERIMENTS.md R6.2);
 //   * the pop is `top != stack` as v_cmpx (the lanes whose stacks are empty drop out of EXEC and of the walking mask in that one
 //     instruction), the push a write under the branch lanes' mask.
 // Per turn with lanes on both the descend and the pop path: 31 vector (2 of them fetches, 2 LDS) and
@@ -37,14 +38,28 @@ namespace shray {
 // One turn: every lane in EXEC (= the walking mask, not empty) visits its node.  Registers: v[2:5] v[6:9] the record
 // { entry.x, entry.y, exit.x, exit.y } { entry.z, exit.z, a, b } (DeviceNode, packed_layout.h), then in place the six differences,
 // the six products; v2 = r0~, v3 = below, then d; v4 = r1~ on the leaf path.  s[64:71]: a record fetched through the scalar cache.
-#define SHRAY_VISIT_TURN(K)                                                                                                      \
+// (-DSHRAY_VISIT_SCALAR=0, an A/B build: every record through the vector memory pipeline -- the throughput form loses 10 %, R6.2)
+#ifndef SHRAY_VISIT_SCALAR
+#define SHRAY_VISIT_SCALAR 1
+#endif
+#if SHRAY_VISIT_SCALAR
+#define SHRAY_VISIT_HEAD(K)                                                                                                      \
     "s_waitcnt lgkmcnt(0)\n\t"                              /* the node the last turn took off the stack */                       \
     "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"              /* node_address(): (name << 3) + octant */                            \
     "v_add_u32_e32 %[L], -1, %[L]\n\t"                      /* lane_count_visit (and the wait state in front of readfirstlane) */ \
     "v_readfirstlane_b32 %[sF], %[A]\n\t"                                                                                       \
     "s_nop 1\n\t"                                           /* a VALU-written SGPR read by a VALU: two wait states */             \
     "v_cmp_ne_u32_e32 vcc, %[sF], %[A]\n\t"                                                                                     \
-    "s_cbranch_vccnz vv" #K "_%=\n\t"                                                                                           \
+    "s_cbranch_vccnz vv" #K "_%=\n\t"
+#else
+#define SHRAY_VISIT_HEAD(K)                                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
+    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"                                                                                  \
+    "v_add_u32_e32 %[L], -1, %[L]\n\t"                                                                                          \
+    "s_branch vv" #K "_%=\n\t"
+#endif
+#define SHRAY_VISIT_TURN(K)                                                                                                      \
+    SHRAY_VISIT_HEAD(K)                                                                                                          \
     "s_load_dwordx8 s[64:71], %[base], %[sF]\n\t"           /* every lane at one record: once, through the scalar cache */       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
     "v_sub_f32_e32 v2, s64, %[Px]\n\t"                                                                                          \

@@ -49,14 +49,41 @@ ORBIT_DRAG = (0.025, 0.010)  # the mouse drag per frame, in window fractions (tr
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # VALU issue peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-instructions / s
-PMC_FILE = os.path.join("profiles", "r05", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
-ISA_COSTS = os.path.join("profiles", "r05", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
-VMEM_MIX = os.path.join("profiles", "r05", "vmem_class_mix.json")  # distinct records per vector-memory instruction, measured (histogram builds)
+PMC_FILE = os.path.join("profiles", "r06", "pmc_headline.json")   # written by profiles/make_pmc_json.py from rocprofv3 --pmc passes
+ISA_COSTS = os.path.join("profiles", "r06", "isa_costs.json")     # written by profiles/isa_costs.py from the kernels' ISA
+VMEM_MIX = os.path.join("profiles", "r06", "vmem_class_mix.json")  # distinct records per vector-memory instruction, measured (histogram builds)
 WARM_SECONDS = 0.15        # back-to-back frames before the first trial, beyond the W warm-up steps: the GPU's clock ramps
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def build_hash():
+    """Hash of the device code of the library this run loads (profiles/buildhash.py), or None."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from buildhash import kernel_source_hash
+        return kernel_source_hash()
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def keyed_input(relative):
+    """A committed input of the roofline object (per-unit instruction costs, the vector-memory class mix): (dict or None, note).  Every
+    such file carries the hash of the device code it was derived from or measured on (`build_hash`), as the counter file does; the
+    note says whether that is this run's device code -- STALE if not."""
+    try:
+        data = json.load(open(os.path.join(ROOT, relative)))
+    except Exception as exc:   # noqa: BLE001
+        return None, f"{relative} unreadable: {exc}"
+    mine, theirs = build_hash(), data.get("build_hash")
+    if theirs is None:
+        return data, f"{relative} (STALE: carries no build hash)"
+    if mine is None:
+        return data, f"{relative} (build hash of this run unknown)"
+    return data, relative + (" (same device code as this build)" if mine == theirs else
+                             f" (STALE: derived from device code {theirs}, this build is {mine})")
 
 
 def orbit_params(pkg, world, width, height, material=0):
@@ -487,6 +514,8 @@ def main():
             ranks[name] = made
         me = ranks[args.root_mode]
         rccl_ranks = min(r.world()[1] for r in ranks.values())
+        for r in ranks.values():
+            r.set_timing(True)      # four stamps per step: where a step's time goes
     else:
         frame_outs = [torch.empty(batch * HEIGHT * WIDTH * 4, dtype=torch.float32, device=device) for _ in range(lanes)]
     trials = max(1, args.trials)
@@ -495,6 +524,7 @@ def main():
     torch.cuda.synchronize()
 
     active = {"rank": me}      # the shray_dist object the loop drives (N > 1: one per root mode)
+    stage_ms = []              # N > 1: per trial, this rank's [render, exchange, assemble] ms (timed_trials)
 
     def views(first, count):
         return [orbit[(first + k) % ORBIT] for k in range(count)]
@@ -558,6 +588,7 @@ def main():
                 break
         ramp_ms = (time.perf_counter() - t0) * 1e3
         seconds = []
+        stage_ms.clear()
         for trial in range(trials):
             fence()
             t0 = time.perf_counter()
@@ -568,8 +599,31 @@ def main():
                 t = torch.tensor([dt], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
+                # the stage stamps of the LAST step each buffer set ran in this trial, averaged over the sets it used
+                used = min(lanes, -(-args.steps // batch))
+                times = [active["rank"].step_times(lane) for lane in range(used)]
+                stage_ms.append([sum(t3[k] for t3 in times) / len(times) for k in range(3)])
             seconds.append(dt)
         return seconds, ramp_ms, ramp_frames
+
+    def stages_report(trial_seconds, rank_obj):
+        """Collective.  The stage times of the median trial on every rank, and the bytes each directed link carries per step."""
+        median_trial = sorted(range(len(trial_seconds)), key=lambda k: trial_seconds[k])[len(trial_seconds) // 2]
+        mine = {"rank": rank, "render_ms": round(stage_ms[median_trial][0], 4), "exchange_ms": round(stage_ms[median_trial][1], 4),
+                "assemble_ms": round(stage_ms[median_trial][2], 4), "link_bytes_to_peer": rank_obj.link_bytes(batch)}
+        everyone = [None] * world_size
+        dist.all_gather_object(everyone, mine)
+        links = [row["link_bytes_to_peer"] for row in everyone]
+        busiest = max((links[a][b], a, b) for a in range(world_size) for b in range(world_size))
+        return {"trial": median_trial, "frames_per_step": batch,
+                "per_rank": [{k: v for k, v in row.items() if k != "link_bytes_to_peer"} for row in everyone],
+                "link_bytes_per_step": links,
+                "busiest_link": {"bytes_per_step": busiest[0], "from": busiest[1], "to": busiest[2],
+                                 "bytes_per_frame": round(busiest[0] / batch, 1)},
+                "into_rank0_bytes_per_step": sum(links[a][0] for a in range(world_size)),
+                "what": "per rank, the last step of each buffer set in the median trial (shray_dist_step_times): render_ms = start -> render + pack "
+                        "done, exchange_ms = -> the set's exchange done (what the step waited for the links, net of the other sets' work it "
+                        "overlapped), assemble_ms = -> de-interleaved; link_bytes_per_step[a][b] = bytes rank a sends to rank b in a step (the plan)"}
 
     def verify_frames():
         """Outside the timed region: one more step, every frame this rank assembled compared bit for bit with a render
@@ -610,6 +664,7 @@ def main():
     trial_s, warm_ms, warm_frames = timed_trials()
     elapsed = sorted(trial_s)[len(trial_s) // 2]
     alt = None
+    stages = stages_report(trial_s, me) if distributed else None
     if distributed:
         for name, r in ranks.items():
             if name == args.root_mode:
@@ -621,6 +676,7 @@ def main():
             alt_elapsed = sorted(alt_s)[len(alt_s) // 2]
             alt = {"mode": name, "value": round(WIDTH * HEIGHT * SPP * args.steps / alt_elapsed / 1e6, 3), "unit": "Mrays/s",
                    "ms_per_step": round(alt_elapsed / args.steps * 1e3, 5), "trial_ms": [round(t * 1e3, 4) for t in alt_s],
+                   "stages": stages_report(alt_s, r),
                    "what": ("every frame gathered on rank 0 (north_star's gather; link-bound at 1 spp: DESIGN.md section 6)"
                             if name == "root0" else "frame f of a step assembled on rank f % N (all-to-all over every xGMI link)")}
         active["rank"] = me
@@ -677,11 +733,7 @@ def main():
                                     "of": "the instance the timed launches run (shray_render_counters_timed)"}
         result["traversals_per_s"] = round(counters_timed["traversals"] * frames_per_s, 1)
         algo_bytes = pkg.tracer.algorithmic_bytes({k: int(v) for k, v in counters.items()}, WIDTH * HEIGHT, normals_fp16=True)
-        costs, costs_note = None, ISA_COSTS
-        try:
-            costs = json.load(open(os.path.join(ROOT, ISA_COSTS)))
-        except Exception as exc:   # noqa: BLE001
-            costs_note = f"{ISA_COSTS} unreadable: {exc}"
+        costs, costs_note = keyed_input(ISA_COSTS)
         gpus = world_size if distributed else 1
         # ---- the roofline object (definition frozen in round 5; DESIGN.md section 5 derives every number) ----------------
         # Three resources, each as achieved / peak with achieved = a COUNT per frame x this run's frames per second:
@@ -699,7 +751,10 @@ def main():
         # profiled run are reported under busy_profiled, named *_busy, and enter no frac.
         algo_gbs = algo_bytes * frames_per_s / 1e9
         roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                "definition": "r05: frac = max over {hbm.frac_measured, vmem.frac, valu.frac}, each = count per frame x frames/s of this run / peak",
+                "definition": "r05: frac = max over {hbm.frac_measured, vmem.frac, valu.frac}, each = count per frame x frames/s of this run / peak; "
+                              "`bound` names the resource with the LARGEST of the three fractions -- it is not a claim about what binds the kernel "
+                              "(R5.1 removed 38 % of the vector-memory instructions and the frame got slower; R6.2: without the scalar-cache path "
+                              "it loses 10 %; DESIGN.md section 5: instruction issue of the waves' own streams, with both pipes two-thirds full)",
                 "hbm": {"algorithmic_bytes_per_frame": algo_bytes, "algorithmic_bytes_per_ray": round(algo_bytes / (WIDTH * HEIGHT * SPP), 1),
                         "algorithmic_gbs": round(algo_gbs, 2), "peak_gbs": HBM_PEAK_GBS * gpus,
                         "algorithmic_over_peak": round(algo_gbs / (HBM_PEAK_GBS * gpus), 4),
@@ -756,10 +811,13 @@ def main():
                 tail = ["--width", str(WIDTH), "--height", str(HEIGHT), "--spp", str(SPP), "--material", str(args.material),
                         "--kernel", str(args.kernel), "--frames-per-launch", str(batch), "--frames-in-flight", str(lanes)] + \
                        (["--same-view"] if args.same_view else [])
+                live_began = time.time()
                 try:
-                    live, live_note = live_counters(tail, batch)
+                    live, live_note = live_counters(tail, batch, budget_s=float(os.environ.get("SHRAY_BENCH_LIVE_BUDGET", "60")))
                 except Exception as exc:   # noqa: BLE001  (a measurement aid must not cost the run its line)
                     live, live_note = None, f"live_counters raised {exc!r}"
+                # (what the counter passes add to the invocation's wall time, after the timed region, is in the line)
+                roof["live_counter_passes_s"] = round(time.time() - live_began, 1)
                 if live:
                     if archived and archived["build_hash"] == kernel_source_hash():
                         for key in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac_profiled", "wait_frac", "serialized_launch_ms",
@@ -794,7 +852,9 @@ def main():
 
             vm = roof["vmem"]
             try:
-                mix = json.load(open(os.path.join(ROOT, VMEM_MIX)))
+                mix, mix_note = keyed_input(VMEM_MIX)
+                if mix is None:
+                    raise RuntimeError(mix_note)
                 per_inst, per_inst_scattered, classes = 0.0, 0.0, {}
                 for kind in mix["kinds"]:
                     for records, share in kind["records_per_instruction"].items():
@@ -807,7 +867,7 @@ def main():
                         per_inst_scattered += kind["share_of_insts"] * share * t_far
                 floor = probe(1, 32)
                 vm.update({"peak_g": round(1.0 / per_inst / 1e9, 2), "peak_scattered_g": round(1.0 / per_inst_scattered / 1e9, 2),
-                           "peak_at_one_record_g": round(1.0 / floor / 1e9, 2), "classes": classes, "mix_source": VMEM_MIX,
+                           "peak_at_one_record_g": round(1.0 / floor / 1e9, 2), "classes": classes, "mix_source": mix_note,
                            "peak_is": "1 / sum over classes (share x seconds per wave-instruction of that class), the classes = the kernel's measured "
                                       "mix of distinct records per instruction, their costs probed in this run (shray_probe_vector_cache, 1 MB table): "
                                       "peak_g with the lanes that share a record in runs of neighbouring lanes (a wave is an 8x8 pixel tile: "
@@ -916,6 +976,8 @@ def main():
     if rank == 0:
         if alt is not None:
             result["alt_root_mode"] = alt
+        if stages is not None:
+            result["stages"] = stages
         print(json.dumps(result), flush=True)
         # the record is out: from here on the watchdog must not add a second one (a hang in the shutdown barrier is the
         # launcher's or the parent's to end)

@@ -151,6 +151,16 @@ int shray_dist_world(shray_dist *dist, int *world, int *communicator_ranks);
  * world == 1: the rank renders whole frames straight into the set's output (no pack, exchange or de-interleave). */
 int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *params, int count, void *hip_stream);
 
+/* Where a step's time goes, for a run that wants to say so (bench.py --gpus N: a sub-linear scaling result then names the
+ * stage -- the reference's loop has one stage, DrawFrame, ray.cpp:1096-1131).  enable != 0: every later step also records
+ * four timing events -- its start, the end of render + pack (hip_stream), the end of the exchange (the communication stream),
+ * the end of the de-interleave.  shray_dist_step_times waits for the set's most recent step and returns the three intervals
+ * in milliseconds: render_ms = start -> packed, exchange_ms = packed -> exchanged (what the step waited for the links, net of
+ * whatever other steps' work the GPU overlapped with it), assemble_ms = exchanged -> finished.  A lone rank (world 1) has
+ * render_ms only.  Either pointer may be NULL.  SHRAY_ERR_INVALID_ARGUMENT if timing was off when that step ran. */
+int shray_dist_set_timing(shray_dist *dist, int enable);
+int shray_dist_step_times(shray_dist *dist, int buffer_set, float *render_ms, float *exchange_ms, float *assemble_ms);
+
 /* After a step on `buffer_set` (and once hip_stream has reached that point): the frames this rank assembled.
  * *assembled frames, the k-th of them frame *first_frame + k * *frame_step of the step, RGBA float32 row 0 = bottom,
  * at *d_rgba + k * width * height * 16 (device memory owned by the object).  The set's next step overwrites that memory:

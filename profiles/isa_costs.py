@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VALU instructions per unit of the shader's own arithmetic, read off the ISA (no GPU needed).
 
-    python profiles/isa_costs.py [out.json]         (default profiles/r04/isa_costs.json)
+    python profiles/isa_costs.py [out.json]         (default profiles/r06/isa_costs.json)
 
 profiles/isa_costs.hip wraps each stage of the per-pixel path -- the product's inline functions, unchanged -- in a
 kernel that runs it once or twice; the difference of the two instances' VALU counts is one repetition of the stage.
@@ -58,7 +58,10 @@ def measure():
 
 
 if __name__ == "__main__":
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "isa_costs.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06", "isa_costs.json")
     costs = measure()
+    # keyed like the counter file: the costs are those of the stages as THIS build's headers compile them (bench.py: keyed_input)
+    from buildhash import kernel_source_hash
+    costs["build_hash"] = kernel_source_hash()
     json.dump(costs, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in costs.items() if k.startswith("c_")}))

@@ -216,6 +216,8 @@ DIST_SYMBOLS = [
     ("shray_dist_destroy", C.c_int, [C.c_void_p]),
     ("shray_dist_world", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("shray_dist_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(FrameParams), C.c_int, C.c_void_p]),
+    ("shray_dist_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("shray_dist_step_times", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("shray_dist_output", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_void_p)]),
     ("shray_dist_copy_output", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -270,7 +270,8 @@ struct BufferSet {
     void *rendered = nullptr, *wire = nullptr, *gather = nullptr, *output = nullptr;
     hipEvent_t packed = nullptr, exchanged = nullptr;
     hipEvent_t finished = nullptr;      // recorded at the end of the last step that used the set, on that step's stream
-    bool used = false;
+    hipEvent_t stamp[4] = {nullptr, nullptr, nullptr, nullptr};   // shray_dist_set_timing: start, packed, exchanged, finished
+    bool used = false, stamped = false;                            // stamped: the set's most recent step recorded its stamps
 };
 
 }   // namespace
@@ -284,6 +285,7 @@ struct shray_dist {
     std::unique_ptr<Transport> transport;
     hipStream_t comm_stream = nullptr;
     std::vector<BufferSet> sets;
+    bool timing = false;
     ~shray_dist()
     {
         (void)hipSetDevice(device);
@@ -295,6 +297,9 @@ struct shray_dist {
             for (void *p : {b.rendered, b.wire, b.gather, b.output})
                 if (p)
                     (void)hipFree(p);
+            for (hipEvent_t e : b.stamp)
+                if (e)
+                    (void)hipEventDestroy(e);
             if (b.packed)
                 (void)hipEventDestroy(b.packed);
             if (b.exchanged)
@@ -497,12 +502,24 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
     if (b.used)
         HIP_TRY(hipStreamWaitEvent(stream, b.finished, 0));
     b.used = true;
+    // shray_dist_set_timing: four stamps per step (timing events, made on first use)
+    const bool stamps = dist->timing;
+    b.stamped = stamps;
+    if (stamps) {
+        for (hipEvent_t &e : b.stamp)
+            if (!e)
+                HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(b.stamp[0], stream));
+    }
 
     if (r.world == 1) {
         // a lone rank owns every tile and assembles every frame (in both root modes): whole frames, row-major, straight
         // into `output` -- the single-GPU path, no pack, no exchange, no de-interleave
         SHRAY_TRY(shray_render_batch_device(dist->scene, params, count, r.width, r.height, dist->spp, nullptr, b.output,
                                             (int64_t)r.width * r.height * 16, stream));
+        if (stamps)
+            for (int k = 1; k < 4; k++)
+                HIP_TRY(hipEventRecord(b.stamp[k], stream));
         HIP_TRY(hipEventRecord(b.finished, stream));
         return SHRAY_OK;
     }
@@ -526,6 +543,9 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
         HIP_TRY(hipGetLastError());
     }
 
+    if (stamps)
+        HIP_TRY(hipEventRecord(b.stamp[1], stream));
+
     // 3. exchange
     // a rank sends at most one transfer per frame and receives (frames it assembles) x (world - 1) <= count + world
     shray_dist_xfer sends[SHRAY_MAX_BATCH + SHRAY_DIST_MAX_WORLD], recvs[SHRAY_MAX_BATCH + SHRAY_DIST_MAX_WORLD];
@@ -546,13 +566,44 @@ int shray_dist_step(shray_dist *dist, int buffer_set, const shray_frame_params *
                 return rc;
         }
     }
+    if (stamps)
+        HIP_TRY(hipEventRecord(b.stamp[2], stream));   // (behind the wait for the exchange: when hip_stream may go on)
 
     // 4. de-interleave the frames this rank assembles
     const int assembled = plan::assembled_frames(r, r.rank, count);
     if (assembled > 0)
         SHRAY_TRY(shray_assemble_tiles_split_device(b.gather, r.world, r.c0, r.c1, assembled, p.channels, p.gather_rank_stride_bytes,
                                                     p.gather_frame_stride_bytes, r.width, r.height, r.tile_w, r.tile_h, b.output, stream));
+    if (stamps)
+        HIP_TRY(hipEventRecord(b.stamp[3], stream));
     HIP_TRY(hipEventRecord(b.finished, stream));
+    return SHRAY_OK;
+}
+
+int shray_dist_set_timing(shray_dist *dist, int enable)
+{
+    if (!dist)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "dist is NULL");
+    dist->timing = enable != 0;
+    return SHRAY_OK;
+}
+
+int shray_dist_step_times(shray_dist *dist, int buffer_set, float *render_ms, float *exchange_ms, float *assemble_ms)
+{
+    if (!dist || buffer_set < 0 || buffer_set >= (int)dist->sets.size())
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_dist_step_times: bad arguments");
+    BufferSet &b = dist->sets[(size_t)buffer_set];
+    if (!b.used || !b.stamped)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "buffer set %d: its most recent step recorded no stamps (shray_dist_set_timing)", buffer_set);
+    HIP_TRY(hipSetDevice(dist->device));
+    HIP_TRY(hipEventSynchronize(b.stamp[3]));
+    float *out[3] = {render_ms, exchange_ms, assemble_ms};
+    for (int k = 0; k < 3; k++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, b.stamp[k], b.stamp[k + 1]));
+        if (out[k])
+            *out[k] = ms;
+    }
     return SHRAY_OK;
 }
 

@@ -195,6 +195,24 @@ class Rank:
         array = (N.FrameParams * count)(*params_list)
         N.check_dist(self._lib.shray_dist_step(self._handle, buffer_set, array, count, C.c_void_p(stream_ptr)))
 
+    def set_timing(self, enable: bool = True):
+        """Later steps record stage stamps (shray_dist_set_timing)."""
+        N.check_dist(self._lib.shray_dist_set_timing(self._handle, 1 if enable else 0))
+
+    def step_times(self, buffer_set: int):
+        """(render_ms, exchange_ms, assemble_ms) of the set's most recent step; waits for it (shray_dist_step_times)."""
+        r, x, a = C.c_float(), C.c_float(), C.c_float()
+        N.check_dist(self._lib.shray_dist_step_times(self._handle, buffer_set, C.byref(r), C.byref(x), C.byref(a)))
+        return r.value, x.value, a.value
+
+    def link_bytes(self, count: int):
+        """[bytes this rank sends to peer p in a step of `count` frames for p in range(world)] (the plan's transfers: host only)."""
+        sends, _recvs, *_ = step_xfers(self.cfg, count)
+        out = [0] * self.cfg.world
+        for peer, _frame, _offset, nbytes in sends:
+            out[peer] += nbytes
+        return out
+
     def output(self, buffer_set: int, count: int):
         """(assembled, first_frame, frame_step, device pointer) after a step of `count` frames."""
         asm, first, step, ptr = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()

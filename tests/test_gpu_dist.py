@@ -298,6 +298,16 @@ def test_bench_launches_its_own_ranks(gpu, tmp_path):
     assert line["rccl_ranks"] == 0 and line["transport_fallback"] is False       # gloo was asked for, nothing fell back
     assert "rotating roots" in line["config"]["parallelism"]
     assert line["alt_root_mode"]["mode"] == "root0" and line["alt_root_mode"]["value"] > 0
+    # where a step's time goes, per rank, and what every directed link carries: both root modes
+    for stages, mode in ((line["stages"], "rotate"), (line["alt_root_mode"]["stages"], "root0")):
+        assert [row["rank"] for row in stages["per_rank"]] == [0, 1]
+        for row in stages["per_rank"]:
+            assert row["render_ms"] > 0 and row["exchange_ms"] >= 0 and row["assemble_ms"] >= 0, (mode, row)
+        links = stages["link_bytes_per_step"]
+        assert len(links) == 2 and links[0][0] == 0 and links[1][1] == 0 and links[1][0] > 0
+        # ROOT0: nothing leaves rank 0; ROTATE: both directions carry tiles
+        assert (links[0][1] == 0) == (mode == "root0"), (mode, links)
+        assert stages["into_rank0_bytes_per_step"] == links[1][0] and stages["busiest_link"]["bytes_per_step"] == max(links[0][1], links[1][0])
     # a rank that fails must fail the command: an impossible frame size is refused by every rank's validation
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--trials", "1",
                           "--width", "0", "--height", "360"], env=env, capture_output=True, text=True, timeout=900)

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_build", "libshader_oracle.so")
+# SHRAY_ORACLE_LIB selects another build of the checker (the sanitizer build, `make -C oracle sanitize`: tests/test_sanitizers.py)
+LIB = os.environ.get("SHRAY_ORACLE_LIB") or os.path.join(HERE, "_build", "libshader_oracle.so")
 REF_HOST = os.path.join(HERE, "_ref", "ref_host")
 
 _lib = None

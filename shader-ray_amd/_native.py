@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB = os.path.join(PKG_DIR, "libshray_host.so")
+# SHRAY_HOST_LIB selects another build of the host layer (the sanitizer build, `make -C shader-ray_amd sanitize`: tests/test_sanitizers.py)
+HOST_LIB = os.environ.get("SHRAY_HOST_LIB") or os.path.join(PKG_DIR, "libshray_host.so")
 DIST_LIB = os.path.join(PKG_DIR, "libshray_dist.so")
 # SHRAY_HIP_LIB selects an experiment build of the same library (profiles/variant_sweep.sh); unset in normal use
 HIP_LIB = os.environ.get("SHRAY_HIP_LIB") or os.path.join(PKG_DIR, "libshray_hip.so")

@@ -160,8 +160,14 @@ world_ptr load_triangles(const std::string &filename)
         }
     } else if (extension == "obj") {
         Obj obj;
+        errno = 0;
         if (!obj.load_object_from_file(filename)) {
-            fprintf(stderr, "Cannot open \"%s\" for input, errno %d\n", filename.c_str(), errno);
+            // the reference prints its "Cannot open" line for every failure of the OBJ reader (world.cpp:83-86); a file that
+            // opened and did not parse says so here ("errno 0" for a parse failure)
+            if (errno != 0)
+                fprintf(stderr, "Cannot open \"%s\" for input, errno %d\n", filename.c_str(), errno);
+            else
+                fprintf(stderr, "Couldn't parse \"%s\" as an OBJ file.\n", filename.c_str());
             return nullptr;
         }
         if (!obj.fill_triangle_set(w->triangles)) {

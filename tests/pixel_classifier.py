@@ -22,7 +22,16 @@ inversesqrt are correctly rounded.  Such differences move a pixel by more than 1
                   (it goes on through the mesh and bounces inside) or hits the other one.  Two pixels of a 1080p frame of the
                   bunny-class mesh, found that way: margins 3.6e-6 and 6.9e-6, where 76 of 2,073,600 pixels are below 1e-5.
 
+  swallowed       the reference's pixel is exactly black -- a NaN through tonemap_and_gamma -- where the oracle's is lit, among
+                  neighbours whose LATER bounces take other paths: the weakly weighted tail of its path ran into one of the shader's
+                  NaN corners (fs:481, fs:130) in the reference's arithmetic.  Pinned by a frame of the reference's own shaders:
+                  million_matte_traps_constant_384 (tests/glsl_cases.py; test_a_nan_in_the_tail_of_a_path_swallows_the_pixel).
+
 A pixel outside 1e-4 that is neither is UNEXPLAINED; tests allow none (tests/test_reference_shader.py).
+
+THE CLASSIFIER IS FROZEN (round 6).  Every arm above is exhibited by a committed frame of the reference's own shaders.  A new way to
+explain a pixel needs such a fixture FIRST -- a small scene, rendered by tests/golden/make_glsl_reference.py, in which the mechanism
+is the only explanation of at least one pixel, and a test that asserts exactly that -- before it may be added here.
 """
 from __future__ import annotations
 

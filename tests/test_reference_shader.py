@@ -205,6 +205,32 @@ def test_pow_of_a_negative_base_is_what_the_reference_frame_shows(all_cases, ora
     assert np.all(np.abs(got - want)[both][:, :3] <= 1e-4 * np.abs(want[both][:, :3]) + 1e-6)
 
 
+def test_a_nan_in_the_tail_of_a_path_swallows_the_pixel(all_cases, oracle_mod):
+    """The classifier's newest arm (`swallowed_by_nan`, tests/pixel_classifier.py) pinned by a frame of the reference's own shaders
+    (VERDICT round 5, item 5).  In the matte 1M-facet sphere one triangle in forty has normals twice as long: fs:481's pow base is
+    negative within 60 degrees of normal incidence on it, its result NaN, and the pixel black (tonemap_and_gamma's max(0, c - .004)
+    of a NaN) WHATEVER the weight of the bounce that hit it -- here the first hit's Fresnel term, a few per cent.  Where the primary
+    ray hits a trap both frames are black.  Where a LATER bounce does, and those bounces are chaotic (sub-pixel facets), the
+    reference's arithmetic and the oracle's land on different facets: the reference's frame has exactly black pixels where the
+    oracle's is lit.  Some of them are explained by nothing else -- their value does not move under the perturbations (the tail
+    weighs nothing unless it is NaN), their first hit and its shadow ray are their neighbours', no triangle test of the oracle's
+    path is near its margin -- and `swallowed_by_nan` is what explains them; none is left unexplained."""
+    import pixel_classifier
+    name = "million_matte_traps_constant_384"
+    case, want = all_cases[name], load_fixture(name)["frame"]
+    verdict = pixel_classifier.classify(oracle_mod, case, want)
+    got = verdict["frame"]
+    black = lambda frame: np.all(frame[..., :3] == 0.0, axis=-1)   # noqa: E731
+    # the traps a primary ray hits: black in both frames, thousands of pixels (2.5 % of the sphere's)
+    assert (black(want) & black(got)).sum() > 1000
+    # the reference's frame black where the oracle's is lit, and the other way round: the chaotic tails
+    assert 3 <= (black(want) & ~black(got)).sum() <= 40 and (black(got) & ~black(want)).sum() <= 40
+    assert verdict["unexplained"] == 0, verdict["worst_unexplained"]
+    assert verdict["swallowed_by_nan"] >= 1, {k: v for k, v in verdict.items() if isinstance(v, (int, float))}
+    # the arm claims nothing that is not exactly black in the reference and lit in the oracle
+    assert verdict["swallowed_by_nan"] <= (black(want) & ~black(got)).sum()
+
+
 def test_the_capped_pixel_of_the_million_triangle_scene_is_the_same_pixel(all_cases, oracle_mod):
     """BASELINE configs[3]'s deep tree runs a few rays into the 400-iteration cap: in the reference's frame and in the
     oracle's the red marker sits on the same pixels, and the oracle's bad-hit counter counts exactly them."""

@@ -241,6 +241,24 @@ int shray_device_tree_download(shray_device_tree *tree, shray_tree_desc *desc, c
 int shray_device_tree_stats(const shray_device_tree *tree, shray_bvh_stats *stats);
 int shray_device_tree_destroy(shray_device_tree *tree);
 
+/* The device-resident scene pipeline (round 6): a tree that shray_bvh_build_device made is flattened and becomes a scene WITHOUT
+ * leaving the device -- no download of the tree, no group tree on the host (world.cpp:46-134 builds one; it can still be had on
+ * demand: shray_device_tree_download + libshray_host's shray_host_adopt_tree), no re-upload:
+ *   shray_flatten_device_tree       get_shader_data (world.cpp:298-347) of the tree where it lies; the tree was built over vertices
+ *                                   of geometry.h:34-38's layout (vertex_stride_floats == 9)
+ *   shray_scene_create_from_device  what shray_scene_create derives on the host from the flattened arrays -- the packed tree and its
+ *                                   eight octant copies, the packed triangles, the pair records, the fp16 normals, the deepest ray
+ *                                   stack -- computed on the device from the tree itself; the arrays equal shray_scene_create's bit for
+ *                                   bit.  `tree` and `flat` may be destroyed afterwards (the scene holds copies). */
+int shray_flatten_device_tree(const shray_device_tree *tree, uint32_t data_texture_width, shray_device_flat **out_flat);
+int shray_scene_create_from_device(const shray_device_tree *tree, const shray_device_flat *flat, shray_scene **out_scene);
+/* For tests and tools: copies the scene's derived arrays back -- the packed nodes (eight copies x nodes x 32 bytes), the packed
+ * triangles (36 bytes each, without the spare record), the fp16 normals -- into caller memory of at least *_bytes bytes (any
+ * pointer may be NULL); *stack_levels = the deepest ray stack the scene's kernels provide for.  Sizes: shray_scene_derived_sizes. */
+int shray_scene_derived_sizes(const shray_scene *scene, uint64_t *packed_nodes_bytes, uint64_t *packed_tris_bytes, uint64_t *normals16_bytes,
+                              uint64_t *pair_nodes_bytes, int32_t *stack_levels);
+int shray_scene_derived_download(const shray_scene *scene, void *packed_nodes, void *packed_tris, void *normals16, void *pair_nodes);
+
 /* Scene ------------------------------------------------------------------ */
 /* Device memory a scene takes besides the reference's own arrays (which stay resident for the literal kernel): 8 x 32 bytes per
  * node (one repacked copy of the tree per ray-direction octant), 36 bytes per triangle, 64 bytes per node for the pair kernel,

@@ -60,6 +60,10 @@ int shray_host_load_triangles(const char *filename, shray_host_world **out_world
 int shray_host_triangles(shray_host_world *world, const int32_t **triangle_vertices, int32_t *triangle_count, const float **vertex_data,
                          int32_t *vertex_count);
 int shray_host_adopt_tree(shray_host_world *world, const shray_tree_desc *tree, const int32_t *triangle_order, double build_seconds);
+/* The build options make_bvh reads from the environment (BVH_MAX_DEPTH, BVH_LEAF_MAX, SAH_CTRAV, SAH_CISEC: bvh.cpp:60-79), as this
+ * process's host builder sees them -- what a caller of shray_bvh_build_device passes on so that both builders follow the same
+ * environment (struct_size is set). */
+int shray_host_bvh_options(shray_bvh_options *options);
 
 /* get_shader_data() (world.h:95).  The arrays named by *desc stay owned by
  * `world` and valid until it is freed.  One flattening is kept per

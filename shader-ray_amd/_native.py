@@ -130,6 +130,11 @@ HIP_SYMBOLS = [
     ("shray_device_tree_download", C.c_int, [C.c_void_p, C.POINTER(TreeDesc), C.POINTER(C.POINTER(C.c_int32))]),
     ("shray_device_tree_stats", C.c_int, [C.c_void_p, C.POINTER(BvhStats)]),
     ("shray_device_tree_destroy", C.c_int, [C.c_void_p]),
+    ("shray_flatten_device_tree", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("shray_scene_create_from_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("shray_scene_derived_sizes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    ("shray_scene_derived_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("shray_render_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(TileSet), C.c_void_p, C.c_void_p]),
     ("shray_render_batch_device", C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -156,6 +161,7 @@ HOST_SYMBOLS = [
     ("shray_host_triangles", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float)),
                                        C.POINTER(C.c_int32)]),
     ("shray_host_adopt_tree", C.c_int, [C.c_void_p, C.POINTER(TreeDesc), C.POINTER(C.c_int32), C.c_double]),
+    ("shray_host_bvh_options", C.c_int, [C.POINTER(BvhOptions)]),
     ("shray_host_get_world_info", C.c_int, [C.c_void_p, C.POINTER(HostWorldInfo)]),
     ("shray_host_flatten", C.c_int, [C.c_void_p, C.c_uint, C.POINTER(SceneDesc)]),
     ("shray_host_export_tree", C.c_int, [C.c_void_p, C.POINTER(TreeDesc)]),

@@ -28,12 +28,14 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <climits>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <vector>
 
+#include "device_tree_internal.h"
 #include "shader_ray_hip.h"
 
 extern "C" int shrayi_fail(int code, const char *message);   // capi.hip: sets shray_last_error()
@@ -104,6 +106,12 @@ struct Tree {   // creation order; 2 count - 1 nodes at most
     int *parent, *negative, *positive, *start, *triangles, *level;
     float *box, *direction;
 };
+
+__global__ void gather_pair(const int *a, const int *b, int *out)
+{
+    out[0] = *a;
+    out[1] = *b;
+}
 
 __global__ void prepare_triangles(Triangles t, const int *__restrict__ triangle_vertices, const float *__restrict__ vertex_data, int stride)
 {
@@ -556,8 +564,12 @@ inline unsigned int blocks_for(int n) { return (unsigned int)((n + kBlock - 1) /
 }   // namespace
 
 struct shray_device_tree {
-    int node_count = 0, triangle_count = 0, vertex_count = 0, leaf_count = 0, max_level = 0, large_leaves = 0;
-    // host copies (shray_device_tree_download)
+    int node_count = 0, triangle_count = 0, vertex_count = 0, vertex_stride = 0, leaf_count = 0, max_level = 0, large_leaves = 0;
+    // The tree STAYS on the device (round 6: shray_flatten_device_tree and shray_scene_create_from_device read it there): the
+    // pre-order arrays, the triangles' vertex indices in post-build order, the build's copy of the vertex data and the order.
+    DeviceArray d_parent, d_negative, d_positive, d_start, d_triangles, d_box, d_direction, d_vertices, d_vertex_data, d_order;
+    // host copies, made by the first shray_device_tree_download
+    bool downloaded = false;
     std::vector<int32_t> parent, negative, positive, start, triangles, order, vertices;
     std::vector<float> box, direction;
     const float *vertex_data = nullptr;
@@ -591,12 +603,21 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
     for (int64_t k = 0; k < (int64_t)3 * triangle_count; k++)
         if (triangle_vertices[k] < 0 || triangle_vertices[k] >= vertex_count)
             return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_bvh_build_device: a triangle names a vertex that does not exist");
+    // non-finite coordinates: the host's fmin / fmax ignore a NaN where the device's keyed atomics would take it (a NaN's key lies
+    // above +inf's), so the two builds would part without a word -- refused
+    for (int64_t v = 0; v < vertex_count; v++)
+        for (int k = 0; k < 3; k++)
+            if (!std::isfinite(vertex_data[v * vertex_stride_floats + k]))
+                return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_bvh_build_device: a vertex coordinate is not finite");
     Options o{30, 10, 1.0f, 4.0f};     // the reference's defaults (bvh.cpp:28-58)
     if (options) {
         o.max_depth = options->max_depth;
-        o.leaf_max = options->leaf_max;
+        // the reference compares a node's count with BVH_LEAF_MAX as UNSIGNED (bvh.cpp:303): a negative value makes every node a leaf
+        o.leaf_max = options->leaf_max < 0 ? INT_MAX - 1 : std::min(options->leaf_max, INT_MAX - 1);
         o.ctrav = options->sah_ctrav;
         o.cisec = options->sah_cisec;
+        if (o.max_depth > 4096 || !std::isfinite(o.ctrav) || !std::isfinite(o.cisec))
+            return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_bvh_build_device: options out of range (max_depth <= 4096, finite SAH costs)");
     }
     const int T = triangle_count, max_nodes = 2 * T;
 
@@ -613,7 +634,8 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
     BVH_TRY(hipEventCreate(&events.began));
     BVH_TRY(hipEventCreate(&events.ended));
     hipEvent_t &began = events.began, &ended = events.ended;
-    DeviceArray d_tv, d_vd, d_box, d_bary, d_original, d_node, d_flag, d_below, d_left, d_right, d_scan_temp;
+    DeviceArray d_tv, d_vd, d_box, d_bary, d_original, d_node, d_flag, d_below, d_left, d_right, d_scan_temp, d_pair;
+    BVH_TRY(d_pair.alloc(8));
     BVH_TRY(d_tv.alloc((size_t)3 * T * 4));
     BVH_TRY(d_vd.alloc((size_t)vertex_count * vertex_stride_floats * 4));
     BVH_TRY(hipMemcpy(d_tv.p, triangle_vertices, (size_t)3 * T * 4, hipMemcpyHostToDevice));
@@ -692,11 +714,11 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
         hipLaunchKernelGGL(emit_nodes, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, l, n, next, total, tree[0]);
         hipLaunchKernelGGL(descend, dim3(blocks_for(T)), dim3(kBlock), 0, nullptr, t, l);
         BVH_TRY(hipGetLastError());
-        // how many nodes split: the last node's offset + its own flag
-        int last_offset = 0, last_split = 0;
-        BVH_TRY(hipMemcpy(&last_offset, l.child_offset + (n - 1), 4, hipMemcpyDeviceToHost));
-        BVH_TRY(hipMemcpy(&last_split, l.split + (n - 1), 4, hipMemcpyDeviceToHost));
-        const int children = 2 * (last_offset + last_split);
+        // how many nodes split: the last node's offset + its own flag (one small kernel gathers the two words, one copy fetches them)
+        hipLaunchKernelGGL(gather_pair, dim3(1), dim3(1), 0, nullptr, l.child_offset + (n - 1), l.split + (n - 1), d_pair.as<int>());
+        int last[2] = {0, 0};
+        BVH_TRY(hipMemcpy(last, d_pair.p, 8, hipMemcpyDeviceToHost));
+        const int children = 2 * (last[0] + last[1]);
         if (total + children > max_nodes)
             return shrayi_fail(SHRAY_ERR_DEVICE, "shray_bvh_build_device: more nodes than a binary tree over the triangles can have");
         total += children;
@@ -729,28 +751,16 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
     made->node_count = total;
     made->triangle_count = T;
     made->vertex_count = vertex_count;
+    made->vertex_stride = vertex_stride_floats;
     made->vertex_data = vertex_data;
     made->seconds = ms * 1e-3;
-    made->parent.resize(total);
+    // the statistics need three words per node (print_bvh_stats, bvh.cpp:83-99); everything else is downloaded when asked for
     made->negative.resize(total);
-    made->positive.resize(total);
-    made->start.resize(total);
     made->triangles.resize(total);
-    made->box.resize((size_t)6 * total);
-    made->direction.resize((size_t)3 * total);
-    made->order.resize(T);
-    made->vertices.resize((size_t)3 * T);
     std::vector<int32_t> levels(total);
-    BVH_TRY(hipMemcpy(made->parent.data(), tree[1].parent, (size_t)total * 4, hipMemcpyDeviceToHost));
     BVH_TRY(hipMemcpy(made->negative.data(), tree[1].negative, (size_t)total * 4, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->positive.data(), tree[1].positive, (size_t)total * 4, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->start.data(), tree[1].start, (size_t)total * 4, hipMemcpyDeviceToHost));
     BVH_TRY(hipMemcpy(made->triangles.data(), tree[1].triangles, (size_t)total * 4, hipMemcpyDeviceToHost));
     BVH_TRY(hipMemcpy(levels.data(), tree[1].level, (size_t)total * 4, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->box.data(), tree[1].box, (size_t)total * 24, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->direction.data(), tree[1].direction, (size_t)total * 12, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->order.data(), t.original, (size_t)T * 4, hipMemcpyDeviceToHost));
-    BVH_TRY(hipMemcpy(made->vertices.data(), d_vertices_out.p, (size_t)T * 12, hipMemcpyDeviceToHost));
     for (int k = 0; k < total; k++) {
         made->max_level = std::max(made->max_level, (int)levels[k]);
         if (made->negative[k] < 0) {
@@ -760,6 +770,17 @@ int shray_bvh_build_device(const int32_t *triangle_vertices, int32_t triangle_co
                 made->large_leaves++;
         }
     }
+    // the renumbered tree, the reordered triangles, the vertex data and the order stay: their buffers change owner
+    std::swap(made->d_parent.p, tr[1][0].p);
+    std::swap(made->d_negative.p, tr[1][1].p);
+    std::swap(made->d_positive.p, tr[1][2].p);
+    std::swap(made->d_start.p, tr[1][3].p);
+    std::swap(made->d_triangles.p, tr[1][4].p);
+    std::swap(made->d_box.p, tr[1][6].p);
+    std::swap(made->d_direction.p, tr[1][7].p);
+    std::swap(made->d_vertices.p, d_vertices_out.p);
+    std::swap(made->d_vertex_data.p, d_vd.p);
+    std::swap(made->d_order.p, d_original.p);
     *out_tree = made.release();
     return SHRAY_OK;
 }
@@ -768,6 +789,28 @@ int shray_device_tree_download(shray_device_tree *tree, shray_tree_desc *desc, c
 {
     if (!tree || !desc)
         return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_device_tree_download: tree or desc is NULL");
+    if (!tree->downloaded) {
+        const size_t n = (size_t)tree->node_count, T = (size_t)tree->triangle_count;
+        tree->parent.resize(n);
+        tree->negative.resize(n);
+        tree->positive.resize(n);
+        tree->start.resize(n);
+        tree->triangles.resize(n);
+        tree->box.resize(6 * n);
+        tree->direction.resize(3 * n);
+        tree->order.resize(T);
+        tree->vertices.resize(3 * T);
+        BVH_TRY(hipMemcpy(tree->parent.data(), tree->d_parent.p, n * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->negative.data(), tree->d_negative.p, n * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->positive.data(), tree->d_positive.p, n * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->start.data(), tree->d_start.p, n * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->triangles.data(), tree->d_triangles.p, n * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->box.data(), tree->d_box.p, n * 24, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->direction.data(), tree->d_direction.p, n * 12, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->order.data(), tree->d_order.p, T * 4, hipMemcpyDeviceToHost));
+        BVH_TRY(hipMemcpy(tree->vertices.data(), tree->d_vertices.p, T * 12, hipMemcpyDeviceToHost));
+        tree->downloaded = true;
+    }
     memset(desc, 0, sizeof(*desc));
     desc->struct_size = sizeof(shray_tree_desc);
     desc->node_count = tree->node_count;
@@ -802,6 +845,18 @@ int shray_device_tree_stats(const shray_device_tree *tree, shray_bvh_stats *stat
 int shray_device_tree_destroy(shray_device_tree *tree)
 {
     delete tree;
+    return SHRAY_OK;
+}
+
+// (internal, device_tree_internal.h)
+int shrayi_device_tree_view(const shray_device_tree *tree, ShrayDeviceTreeView *view)
+{
+    if (!tree || !view)
+        return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "device tree is NULL");
+    *view = ShrayDeviceTreeView{tree->node_count, tree->triangle_count, tree->vertex_count, tree->vertex_stride, tree->max_level,
+                                tree->d_parent.as<int>(), tree->d_negative.as<int>(), tree->d_positive.as<int>(), tree->d_start.as<int>(),
+                                tree->d_triangles.as<int>(), tree->d_box.as<float>(), tree->d_direction.as<float>(),
+                                tree->d_vertices.as<int>(), tree->d_vertex_data.as<float>()};
     return SHRAY_OK;
 }
 

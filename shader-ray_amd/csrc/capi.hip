@@ -16,6 +16,7 @@
 #include "frame_params_defaults.h"
 #include "launch.h"
 #include "packed_layout.h"
+#include "device_tree_internal.h"
 #include "shader_ray_hip.h"
 
 using namespace shray;
@@ -46,7 +47,7 @@ int fail(int code, const char *fmt, ...)
 const float kTerminatorF = 16777215.0f;   // raytracer.es.fs:384
 
 // binary32 -> binary16 bits, round to nearest even (GL_RGB16F upload, ray.cpp:474)
-uint16_t float_to_half_bits(float f)
+__host__ __device__ uint16_t float_to_half_bits(float f)
 {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -95,6 +96,17 @@ struct DeviceBuffer {
         // the fill runs on the null stream, which non-blocking streams do not wait for: finish it here, before
         // any kernel or copy on another stream can touch the buffer
         return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+    }
+    // `bytes` of device memory, uninitialised, or a copy of device memory (shray_scene_create_from_device; null stream)
+    hipError_t reserve(size_t bytes)
+    {
+        release();
+        return hipMalloc(&p, bytes ? bytes : 16);
+    }
+    hipError_t copy_of(const void *device_src, size_t bytes)
+    {
+        const hipError_t e = reserve(bytes);
+        return (e != hipSuccess || !bytes) ? e : hipMemcpyAsync(p, device_src, bytes, hipMemcpyDeviceToDevice, nullptr);
     }
 };
 
@@ -1040,6 +1052,312 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
     v.env_w = v.env_h = 0;
 
     *out_scene = s.release();
+    return SHRAY_OK;
+}
+
+// ---- the same scene from a tree that never left the device ----------------------------------------------------------------
+// shray_bvh_build_device -> shray_flatten_device_tree -> here (round 6; SURVEY 8(f) rank 3: scene turnaround,
+// world.cpp:46-134, :298-347; bvh.cpp:288-358).  shray_scene_create takes the reference's arrays from the HOST, proves that the
+// eight (hit, miss) tables are one threaded binary tree (TreeBuilder) and derives the packed tree, its eight octant copies, the
+// packed triangles, the pair records and the fp16 normals on the host.  Here the tree exists as arrays already -- the tables were
+// threaded FROM it, by flatten.hip, so there is nothing to recover --, and everything derived from it is computed where it lies:
+// one thread per node / triangle / corner.  Packed order = the tree's pre-order (TreeBuilder::pack walks the same way: a node,
+// its negative subtree, its positive subtree).  The arrays equal shray_scene_create's bit for bit (tests/test_gpu_scene_device.py
+// reads both back).
+namespace {
+
+struct SceneFromDeviceFacts {     // what the kernels report back: 16 bytes, one copy
+    int depth;                    // deepest ray stack over the eight direction codes (TreeBuilder::tables_match's `depth`)
+    uint32_t largest_leaf;
+    int coords_out_of_range;      // a box coordinate outside exact_div.h's operand ranges
+    int not_canonical;            // a split direction that is not a positive unit axis vector
+};
+
+__global__ void sd_pack_nodes(int n, const int *__restrict__ negative, const int *__restrict__ positive, const int *__restrict__ start,
+                              const int *__restrict__ triangles, const float *__restrict__ direction, const int *__restrict__ index_of,
+                              const float *__restrict__ boxmin, const float *__restrict__ boxmax, PackedNode *__restrict__ nodes,
+                              PackedNode *__restrict__ copies, SceneFromDeviceFacts *facts)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const size_t me = (size_t)index_of[k];
+    PackedNode pn;
+    for (int a = 0; a < 3; a++) {
+        pn.lo[a] = boxmin[3 * me + a];
+        pn.hi[a] = boxmax[3 * me + a];
+        const float lo_m = fabsf(pn.lo[a]), hi_m = fabsf(pn.hi[a]);
+        if (!(pn.lo[a] == 0.0f || (lo_m >= 0x1p-70f && lo_m < 0x1p60f)) || !(pn.hi[a] == 0.0f || (hi_m >= 0x1p-70f && hi_m < 0x1p60f)))
+            facts->coords_out_of_range = 1;
+    }
+    uint32_t axis = 0;
+    if (negative[k] >= 0) {
+        // a branch: the split direction is a positive unit axis vector (bvh.cpp:213-228 and bvh_build.hip make no other); the
+        // child a ray of direction code 0 visits first is then the positive one (world.cpp:259-265), which is how TreeBuilder
+        // tells the children apart
+        const float *d = direction + 3 * (size_t)k;
+        const int nonzero = (d[0] != 0.0f) + (d[1] != 0.0f) + (d[2] != 0.0f);
+        axis = d[0] != 0.0f ? 0u : (d[1] != 0.0f ? 1u : 2u);
+        if (nonzero != 1 || !(d[axis] > 0.0f))
+            facts->not_canonical = 1;
+        pn.a = (axis << 30) | (uint32_t)positive[k];
+        pn.b = (uint32_t)negative[k];
+    } else {
+        pn.a = (uint32_t)start[k];
+        pn.b = kLeafFlag | (uint32_t)triangles[k];
+        atomicMax(&facts->largest_leaf, (uint32_t)triangles[k]);
+    }
+    nodes[k] = pn;
+    // the eight octant copies (packed_layout.h), exactly as shray_scene_create makes them
+    for (uint32_t o = 0; o < 8; o++) {
+        PackedNode c = pn;
+        for (int a = 0; a < 3; a++)
+            if (!((o >> a) & 1u)) {
+                const float t = c.lo[a];
+                c.lo[a] = c.hi[a];
+                c.hi[a] = t;
+            }
+        if (!(c.b & kLeafFlag)) {
+            const uint32_t pos = (c.a & kChildMask) << (kNodeShift - kNodeNameShift), neg = c.b << (kNodeShift - kNodeNameShift);
+            const bool negative_first = (o >> axis) & 1u;
+            c.a = (1u << (kAxisHotShift + axis)) | (negative_first ? neg : pos);
+            c.b = negative_first ? pos : neg;
+        }
+        DeviceNode dn;
+        dn.entry_xy[0] = c.lo[0];
+        dn.entry_xy[1] = c.lo[1];
+        dn.exit_xy[0] = c.hi[0];
+        dn.exit_xy[1] = c.hi[1];
+        dn.z[0] = c.lo[2];
+        dn.z[1] = c.hi[2];
+        dn.a = c.a;
+        dn.b = c.b;
+        *reinterpret_cast<DeviceNode *>(&copies[(size_t)o * n + k]) = dn;
+    }
+}
+
+// the deepest stack any ray can ask for: at a branch g a ray of direction code c holds one pending far child for every ancestor
+// (g included) whose NEAR child its path went through (TreeBuilder::tables_match counts the same while it re-threads)
+__global__ void sd_stack_depth(int n, const int *__restrict__ parent, const int *__restrict__ negative, const PackedNode *__restrict__ nodes,
+                               SceneFromDeviceFacts *facts)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n || negative[g] < 0)
+        return;
+    int pending[8] = {1, 1, 1, 1, 1, 1, 1, 1};      // g's own far child
+    for (int child = g, p = parent[g]; p >= 0; child = p, p = parent[p]) {
+        const uint32_t axis = nodes[p].a >> 30;
+        const bool child_is_negative = child == negative[p];
+        for (int c = 0; c < 8; c++)
+            pending[c] += (((c >> axis) & 1) != 0) == child_is_negative ? 1 : 0;    // code bit set: the negative child is the near one
+    }
+    int deepest = 0;
+    for (int c = 0; c < 8; c++)
+        deepest = max(deepest, pending[c]);
+    atomicMax(&facts->depth, deepest);
+}
+
+__global__ void sd_pack_triangles(size_t nt, const float *__restrict__ positions, PackedTri *__restrict__ tris)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nt)
+        return;
+    PackedTri pt;
+    memset(&pt, 0, sizeof(pt));
+    if (t < nt) {           // (t == nt: the spare record behind the last triangle, zeros)
+        const float *v = positions + 9 * t;
+        for (int a = 0; a < 3; a++) {
+            pt.v0[a] = v[a];
+            pt.e0[a] = v[3 + a] - v[a];        // e0 = v1 - v0, raytracer.es.fs:304
+            pt.e1[a] = v[a] - v[6 + a];        // e1 = v0 - v2, raytracer.es.fs:305
+        }
+    }
+    tris[t] = pt;
+}
+
+__global__ void sd_half_normals(size_t count, const float *__restrict__ normals, uint16_t *__restrict__ halves)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count)
+        halves[k] = float_to_half_bits(normals[k]);
+}
+
+__device__ uint32_t sd_pair_link(const PackedNode *nodes, uint32_t child, uint32_t *info)
+{
+    const PackedNode &c = nodes[child];
+    if (c.b & kLeafFlag) {
+        const uint32_t count = c.b & ~kLeafFlag;
+        *info = c.a;
+        return child | (min(count, kPairCountMask) << kPairCountShift) | kLeafFlag;
+    }
+    *info = 0;
+    return child | ((c.a >> 30) << kPairAxisShift);
+}
+
+__global__ void sd_pair_records(int n, const PackedNode *__restrict__ nodes, PackedPair *__restrict__ pairs)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    PackedPair pp;
+    memset(&pp, 0, sizeof(pp));
+    const PackedNode pn = nodes[k];
+    if (!(pn.b & kLeafFlag)) {
+        const uint32_t pos = pn.a & kChildMask, neg = pn.b;
+        for (int a = 0; a < 3; a++) {
+            pp.lo0[a] = nodes[neg].lo[a];
+            pp.hi0[a] = nodes[neg].hi[a];
+            pp.lo1[a] = nodes[pos].lo[a];
+            pp.hi1[a] = nodes[pos].hi[a];
+        }
+        pp.link0 = sd_pair_link(nodes, neg, &pp.info0);
+        pp.link1 = sd_pair_link(nodes, pos, &pp.info1);
+    }
+    pairs[k] = pp;
+}
+
+}   // namespace
+
+int shray_scene_create_from_device(const shray_device_tree *tree, const shray_device_flat *flat, shray_scene **out_scene)
+{
+    if (!tree || !flat || !out_scene)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "tree, flat or out_scene is NULL");
+    *out_scene = nullptr;
+    ShrayDeviceTreeView t;
+    ShrayDeviceFlatView f;
+    if (const int rc = shrayi_device_tree_view(tree, &t))
+        return rc;
+    if (const int rc = shrayi_device_flat_view(flat, &f))
+        return rc;
+    const shray_scene_desc &desc = f.desc;
+    if (desc.group_count != t.node_count || desc.vertex_count != 3u * (uint32_t)t.triangle_count || !f.index_of)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "the flattened arrays are not those of this tree (%d nodes / %d, %u corners / %d triangles)",
+                    desc.group_count, t.node_count, desc.vertex_count, t.triangle_count);
+    const uint64_t stride = (uint64_t)desc.data_texture_width * (uint64_t)desc.group_data_rows;
+    // the shader's float32 indices (shray_scene_create)
+    if (stride * 8 > 16777216ull || desc.vertex_count > 16777216u)
+        return fail(SHRAY_ERR_INDEX_RANGE, "scene too large for float32 indices (%llu link texels, %u vertices; limit 2^24)",
+                    (unsigned long long)(stride * 8), desc.vertex_count);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return fail(SHRAY_ERR_NO_DEVICE, "no HIP device is available (hipGetDevice failed)");
+
+    std::unique_ptr<shray_scene> s(new shray_scene);
+    s->device = device;
+    const size_t nv = desc.vertex_count, ng = (size_t)desc.group_count, nt = nv / 3;
+    const int n = t.node_count, block = 256;
+
+    // the reference's arrays (the literal kernel's inputs): copies on the device
+    HIP_TRY(s->positions.copy_of(desc.vertex_positions, nv * 12));
+    HIP_TRY(s->normals32.copy_of(desc.vertex_normals, nv * 12));
+    HIP_TRY(s->boxmin.copy_of(desc.group_boxmin, ng * 12));
+    HIP_TRY(s->boxmax.copy_of(desc.group_boxmax, ng * 12));
+    HIP_TRY(s->objects.copy_of(desc.group_objects, ng * 8));
+    HIP_TRY(s->hitmiss.copy_of(desc.group_hitmiss, (size_t)stride * 8 * 8));
+    HIP_TRY(s->counters.upload(nullptr, sizeof(DeviceCounters) * kCounterShards));
+    HIP_TRY(s->normals16.reserve(nv * 3 * 2));
+    if (nv)
+        hipLaunchKernelGGL(sd_half_normals, dim3((unsigned)((nv * 3 + block - 1) / block)), dim3(block), 0, nullptr, nv * 3,
+                           (const float *)s->normals32.p, (uint16_t *)s->normals16.p);
+
+    // the packed tree, its octant copies, the packed triangles, the pair records
+    DeviceBuffer d_nodes, d_facts;
+    HIP_TRY(d_nodes.reserve((size_t)n * sizeof(PackedNode)));
+    HIP_TRY(d_facts.upload(nullptr, sizeof(SceneFromDeviceFacts)));
+    HIP_TRY(s->packed_nodes.reserve((size_t)n * 8 * sizeof(PackedNode)));
+    HIP_TRY(s->packed_tris.reserve((nt + 1) * sizeof(PackedTri)));
+    const dim3 node_grid((unsigned)((n + block - 1) / block));
+    hipLaunchKernelGGL(sd_pack_nodes, node_grid, dim3(block), 0, nullptr, n, t.negative, t.positive, t.start, t.triangles, t.direction, f.index_of,
+                       desc.group_boxmin, desc.group_boxmax, (PackedNode *)d_nodes.p, (PackedNode *)s->packed_nodes.p,
+                       (SceneFromDeviceFacts *)d_facts.p);
+    hipLaunchKernelGGL(sd_stack_depth, node_grid, dim3(block), 0, nullptr, n, t.parent, t.negative, (const PackedNode *)d_nodes.p,
+                       (SceneFromDeviceFacts *)d_facts.p);
+    hipLaunchKernelGGL(sd_pack_triangles, dim3((unsigned)((nt + 1 + block - 1) / block)), dim3(block), 0, nullptr, nt,
+                       (const float *)s->positions.p, (PackedTri *)s->packed_tris.p);
+    const bool pairs = (size_t)n <= (size_t)kPairIndexMask + 1;
+    if (pairs) {
+        HIP_TRY(s->pair_nodes.reserve((size_t)n * sizeof(PackedPair)));
+        hipLaunchKernelGGL(sd_pair_records, node_grid, dim3(block), 0, nullptr, n, (const PackedNode *)d_nodes.p, (PackedPair *)s->pair_nodes.p);
+    }
+    HIP_TRY(hipGetLastError());
+    SceneFromDeviceFacts facts;
+    HIP_TRY(hipMemcpy(&facts, d_facts.p, sizeof(facts), hipMemcpyDeviceToHost));   // (waits for the kernels and copies above)
+    if (facts.not_canonical)
+        return fail(SHRAY_ERR_BAD_TREE, "a split direction of the device tree is not a positive unit axis vector: take the host path "
+                                        "(shray_device_tree_download, shray_scene_create)");
+    s->view.packed_nodes_bytes = (uint32_t)((size_t)n * sizeof(PackedNode));
+    s->view.packed_root = 0;      // pre-order: the root is record 0
+    if (pairs) {
+        s->max_leaf_count = facts.largest_leaf;
+        // (the root's own link: a leaf root names its triangles, a branch root its split axis -- one record read back)
+        PackedNode root;
+        HIP_TRY(hipMemcpy(&root, d_nodes.p, sizeof(root), hipMemcpyDeviceToHost));
+        s->view.pair_root_link = (root.b & kLeafFlag) ? (0u | (std::min(root.b & ~kLeafFlag, kPairCountMask) << kPairCountShift) | kLeafFlag)
+                                                      : (0u | ((root.a >> 30) << kPairAxisShift));
+        uint32_t bits = 1;
+        while ((1ull << bits) < (size_t)n)
+            bits++;
+        s->view.pair_index_bits = bits;
+    }
+    s->view.exact_div_ok = facts.coords_out_of_range ? 0u : 1u;
+    s->stack_levels = std::max(3, facts.depth);
+    s->packed_ok = true;
+
+    SceneView &v = s->view;
+    v.positions = (const float *)s->positions.p;
+    v.normals16 = (const uint16_t *)s->normals16.p;
+    v.normals32 = (const float *)s->normals32.p;
+    v.boxmin = (const float *)s->boxmin.p;
+    v.boxmax = (const float *)s->boxmax.p;
+    v.hitmiss = (const float *)s->hitmiss.p;
+    v.objects = (const float *)s->objects.p;
+    v.table_stride = (uint32_t)stride;
+    v.group_count = (uint32_t)ng;
+    v.triangle_count = (uint32_t)nt;
+    v.tree_root = (float)desc.tree_root;
+    v.packed_nodes = s->packed_nodes.p;
+    v.packed_tris = s->packed_tris.p;
+    v.pair_nodes = s->pair_nodes.p;
+    v.env = nullptr;
+    v.env_w = v.env_h = 0;
+    *out_scene = s.release();
+    return SHRAY_OK;
+}
+
+int shray_scene_derived_sizes(const shray_scene *scene, uint64_t *packed_nodes_bytes, uint64_t *packed_tris_bytes, uint64_t *normals16_bytes,
+                              uint64_t *pair_nodes_bytes, int32_t *stack_levels)
+{
+    if (!scene)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene is NULL");
+    const SceneView &v = scene->view;
+    if (packed_nodes_bytes)
+        *packed_nodes_bytes = scene->packed_ok ? (uint64_t)v.packed_nodes_bytes * 8u : 0u;
+    if (packed_tris_bytes)
+        *packed_tris_bytes = scene->packed_ok ? (uint64_t)v.triangle_count * sizeof(PackedTri) : 0u;
+    if (normals16_bytes)
+        *normals16_bytes = (uint64_t)v.triangle_count * 3u * 3u * 2u;
+    if (pair_nodes_bytes)
+        *pair_nodes_bytes = (scene->packed_ok && scene->pair_nodes.p) ? (uint64_t)(v.packed_nodes_bytes / sizeof(PackedNode)) * sizeof(PackedPair) : 0u;
+    if (stack_levels)
+        *stack_levels = scene->stack_levels;
+    return SHRAY_OK;
+}
+
+int shray_scene_derived_download(const shray_scene *scene, void *packed_nodes, void *packed_tris, void *normals16, void *pair_nodes)
+{
+    if (!scene)
+        return fail(SHRAY_ERR_INVALID_ARGUMENT, "scene is NULL");
+    uint64_t a = 0, b = 0, c = 0, d = 0;
+    shray_scene_derived_sizes(scene, &a, &b, &c, &d, nullptr);
+    HIP_TRY(hipSetDevice(scene->device));
+    if (packed_nodes && a)
+        HIP_TRY(hipMemcpy(packed_nodes, scene->packed_nodes.p, a, hipMemcpyDeviceToHost));
+    if (packed_tris && b)
+        HIP_TRY(hipMemcpy(packed_tris, scene->packed_tris.p, b, hipMemcpyDeviceToHost));
+    if (normals16 && c)
+        HIP_TRY(hipMemcpy(normals16, scene->normals16.p, c, hipMemcpyDeviceToHost));
+    if (pair_nodes && d)
+        HIP_TRY(hipMemcpy(pair_nodes, scene->pair_nodes.p, d, hipMemcpyDeviceToHost));
     return SHRAY_OK;
 }
 

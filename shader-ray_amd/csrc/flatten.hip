@@ -22,6 +22,7 @@
 #include <memory>
 #include <vector>
 
+#include "device_tree_internal.h"
 #include "shader_ray_hip.h"
 
 extern "C" int shrayi_fail(int code, const char *message);   // capi.hip: sets shray_last_error()
@@ -148,6 +149,7 @@ __global__ void thread_links(TreeView t, const int *__restrict__ index_of, float
 struct shray_device_flat {
     shray_scene_desc desc{};   // device pointers
     DeviceArray positions, normals, colors, boxmin, boxmax, directions, children, hitmiss, objects;
+    DeviceArray index_of;      // pre-order node -> its in-order number (kept for shray_scene_create_from_device)
     std::vector<float> host[9];
 };
 
@@ -160,6 +162,64 @@ struct shray_device_flat {
             return shrayi_fail(e_ == hipErrorOutOfMemory ? SHRAY_ERR_OUT_OF_MEMORY : SHRAY_ERR_DEVICE, msg_); \
         }                                                                                                        \
     } while (0)
+
+// The flattening proper: the tree and the mesh are on the device already.
+static int flatten_on_device(const TreeView &view, const int *d_tri_vertices, const float *d_vertex_data, int tris, uint32_t width,
+                             shray_device_flat **out_flat)
+{
+    const int n = view.node_count;
+    std::unique_ptr<shray_device_flat> flat(new shray_device_flat);
+    const uint32_t corners = 3u * (uint32_t)tris;
+    const uint32_t vertex_rows = (corners + width - 1) / width;
+    const int node_rows = (int)(((uint32_t)n + width - 1) / width);
+    const size_t vertex_texels = (size_t)width * vertex_rows, node_texels = (size_t)width * node_rows;
+
+    FLAT_TRY(flat->index_of.zeros(sizeof(int) * (size_t)n));
+    FLAT_TRY(flat->positions.zeros(sizeof(float) * 3 * vertex_texels));
+    FLAT_TRY(flat->normals.zeros(sizeof(float) * 3 * vertex_texels));
+    FLAT_TRY(flat->colors.zeros(sizeof(float) * 3 * vertex_texels));
+    FLAT_TRY(flat->boxmin.zeros(sizeof(float) * 3 * node_texels));
+    FLAT_TRY(flat->boxmax.zeros(sizeof(float) * 3 * node_texels));
+    FLAT_TRY(flat->directions.zeros(sizeof(float) * 3 * node_texels));
+    FLAT_TRY(flat->children.zeros(sizeof(float) * 2 * node_texels));
+    FLAT_TRY(flat->objects.zeros(sizeof(float) * 2 * node_texels));
+    FLAT_TRY(flat->hitmiss.zeros(sizeof(float) * 16 * node_texels));
+
+    const int block = 256;
+    if (corners)
+        hipLaunchKernelGGL(expand_corners, dim3((corners + block - 1) / block), dim3(block), 0, nullptr, (int)corners, d_tri_vertices,
+                           d_vertex_data, (float *)flat->positions.p, (float *)flat->colors.p, (float *)flat->normals.p);
+    const dim3 node_grid((n + block - 1) / block);
+    int *d_index = (int *)flat->index_of.p;
+    hipLaunchKernelGGL(number_nodes, node_grid, dim3(block), 0, nullptr, view, d_index);
+    hipLaunchKernelGGL(store_nodes, node_grid, dim3(block), 0, nullptr, view, (const int *)d_index, (float *)flat->boxmin.p,
+                       (float *)flat->boxmax.p, (float *)flat->directions.p, (float *)flat->children.p, (float *)flat->objects.p);
+    hipLaunchKernelGGL(thread_links, dim3(node_grid.x, 8), dim3(block), 0, nullptr, view, (const int *)d_index,
+                       (float *)flat->hitmiss.p, 2 * node_texels);
+    FLAT_TRY(hipGetLastError());
+    int root_index = 0;
+    FLAT_TRY(hipMemcpy(&root_index, d_index, sizeof(int), hipMemcpyDeviceToHost));   // also waits for the kernels
+
+    shray_scene_desc &d = flat->desc;
+    d.struct_size = (uint32_t)sizeof(d);
+    d.data_texture_width = width;
+    d.vertex_count = corners;
+    d.vertex_data_rows = vertex_rows;
+    d.vertex_positions = (const float *)flat->positions.p;
+    d.vertex_normals = (const float *)flat->normals.p;
+    d.vertex_colors = (const float *)flat->colors.p;
+    d.group_count = n;
+    d.group_data_rows = node_rows;
+    d.tree_root = root_index;
+    d.group_boxmin = (const float *)flat->boxmin.p;
+    d.group_boxmax = (const float *)flat->boxmax.p;
+    d.group_directions = (const float *)flat->directions.p;
+    d.group_children = (const float *)flat->children.p;
+    d.group_hitmiss = (const float *)flat->hitmiss.p;
+    d.group_objects = (const float *)flat->objects.p;
+    *out_flat = flat.release();
+    return SHRAY_OK;
+}
 
 extern "C" {
 
@@ -193,13 +253,7 @@ int shray_flatten_device(const shray_tree_desc *tree, uint32_t width, shray_devi
         if (tree->triangle_vertices[k] < 0 || tree->triangle_vertices[k] >= tree->vertex_count)
             return shrayi_fail(SHRAY_ERR_BAD_TREE, "tree: a triangle names a vertex outside the mesh");
 
-    std::unique_ptr<shray_device_flat> flat(new shray_device_flat);
-    const uint32_t corners = 3u * (uint32_t)tris;
-    const uint32_t vertex_rows = (corners + width - 1) / width;
-    const int node_rows = (int)(((uint32_t)n + width - 1) / width);
-    const size_t vertex_texels = (size_t)width * vertex_rows, node_texels = (size_t)width * node_rows;
-
-    DeviceArray d_parent, d_negative, d_positive, d_start, d_triangles, d_box, d_direction, d_tri_vertices, d_vertex_data, d_index;
+    DeviceArray d_parent, d_negative, d_positive, d_start, d_triangles, d_box, d_direction, d_tri_vertices, d_vertex_data;
     FLAT_TRY(d_parent.upload(tree->node_parent, sizeof(int) * (size_t)n));
     FLAT_TRY(d_negative.upload(tree->node_negative, sizeof(int) * (size_t)n));
     FLAT_TRY(d_positive.upload(tree->node_positive, sizeof(int) * (size_t)n));
@@ -207,55 +261,29 @@ int shray_flatten_device(const shray_tree_desc *tree, uint32_t width, shray_devi
     FLAT_TRY(d_triangles.upload(tree->node_triangles, sizeof(int) * (size_t)n));
     FLAT_TRY(d_box.upload(tree->node_box, sizeof(float) * 6 * (size_t)n));
     FLAT_TRY(d_direction.upload(tree->node_direction, sizeof(float) * 3 * (size_t)n));
-    FLAT_TRY(d_tri_vertices.upload(tree->triangle_vertices, sizeof(int) * (size_t)corners));
+    FLAT_TRY(d_tri_vertices.upload(tree->triangle_vertices, sizeof(int) * 3 * (size_t)tris));
     FLAT_TRY(d_vertex_data.upload(tree->vertex_data, sizeof(float) * 9 * (size_t)tree->vertex_count));
-    FLAT_TRY(d_index.zeros(sizeof(int) * (size_t)n));
-    FLAT_TRY(flat->positions.zeros(sizeof(float) * 3 * vertex_texels));
-    FLAT_TRY(flat->normals.zeros(sizeof(float) * 3 * vertex_texels));
-    FLAT_TRY(flat->colors.zeros(sizeof(float) * 3 * vertex_texels));
-    FLAT_TRY(flat->boxmin.zeros(sizeof(float) * 3 * node_texels));
-    FLAT_TRY(flat->boxmax.zeros(sizeof(float) * 3 * node_texels));
-    FLAT_TRY(flat->directions.zeros(sizeof(float) * 3 * node_texels));
-    FLAT_TRY(flat->children.zeros(sizeof(float) * 2 * node_texels));
-    FLAT_TRY(flat->objects.zeros(sizeof(float) * 2 * node_texels));
-    FLAT_TRY(flat->hitmiss.zeros(sizeof(float) * 16 * node_texels));
-
     const TreeView view{n, (const int *)d_parent.p, (const int *)d_negative.p, (const int *)d_positive.p, (const int *)d_start.p,
                         (const int *)d_triangles.p, (const float *)d_box.p, (const float *)d_direction.p};
-    const int block = 256;
-    if (corners)
-        hipLaunchKernelGGL(expand_corners, dim3((corners + block - 1) / block), dim3(block), 0, nullptr, (int)corners,
-                           (const int *)d_tri_vertices.p, (const float *)d_vertex_data.p, (float *)flat->positions.p,
-                           (float *)flat->colors.p, (float *)flat->normals.p);
-    const dim3 node_grid((n + block - 1) / block);
-    hipLaunchKernelGGL(number_nodes, node_grid, dim3(block), 0, nullptr, view, (int *)d_index.p);
-    hipLaunchKernelGGL(store_nodes, node_grid, dim3(block), 0, nullptr, view, (const int *)d_index.p, (float *)flat->boxmin.p,
-                       (float *)flat->boxmax.p, (float *)flat->directions.p, (float *)flat->children.p, (float *)flat->objects.p);
-    hipLaunchKernelGGL(thread_links, dim3(node_grid.x, 8), dim3(block), 0, nullptr, view, (const int *)d_index.p,
-                       (float *)flat->hitmiss.p, 2 * node_texels);
-    FLAT_TRY(hipGetLastError());
-    int root_index = 0;
-    FLAT_TRY(hipMemcpy(&root_index, d_index.p, sizeof(int), hipMemcpyDeviceToHost));   // also waits for the kernels
+    return flatten_on_device(view, (const int *)d_tri_vertices.p, (const float *)d_vertex_data.p, tris, width, out_flat);
+}
 
-    shray_scene_desc &d = flat->desc;
-    d.struct_size = (uint32_t)sizeof(d);
-    d.data_texture_width = width;
-    d.vertex_count = corners;
-    d.vertex_data_rows = vertex_rows;
-    d.vertex_positions = (const float *)flat->positions.p;
-    d.vertex_normals = (const float *)flat->normals.p;
-    d.vertex_colors = (const float *)flat->colors.p;
-    d.group_count = n;
-    d.group_data_rows = node_rows;
-    d.tree_root = root_index;
-    d.group_boxmin = (const float *)flat->boxmin.p;
-    d.group_boxmax = (const float *)flat->boxmax.p;
-    d.group_directions = (const float *)flat->directions.p;
-    d.group_children = (const float *)flat->children.p;
-    d.group_hitmiss = (const float *)flat->hitmiss.p;
-    d.group_objects = (const float *)flat->objects.p;
-    *out_flat = flat.release();
-    return SHRAY_OK;
+/* The same for a tree that IS on the device (shray_bvh_build_device's): nothing is uploaded, nothing validated on the host -- the
+ * builder made the pre-order shape the kernels rely on. */
+int shray_flatten_device_tree(const shray_device_tree *tree, uint32_t width, shray_device_flat **out_flat)
+{
+    if (!tree || !out_flat || width == 0)
+        return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_flatten_device_tree: NULL argument or zero texture width");
+    *out_flat = nullptr;
+    ShrayDeviceTreeView t;
+    const int rc = shrayi_device_tree_view(tree, &t);
+    if (rc)
+        return rc;
+    if (t.vertex_stride_floats != 9)
+        return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "shray_flatten_device_tree: the tree was built over vertices of another layout than "
+                                                      "position, colour, normal (9 floats, geometry.h:34-38)");
+    const TreeView view{t.node_count, t.parent, t.negative, t.positive, t.start, t.triangles, t.box, t.direction};
+    return flatten_on_device(view, t.triangle_vertices, t.vertex_data, t.triangle_count, width, out_flat);
 }
 
 int shray_device_flat_describe(const shray_device_flat *flat, shray_scene_desc *desc)
@@ -299,6 +327,16 @@ int shray_device_flat_download(shray_device_flat *flat, shray_scene_desc *desc)
 int shray_device_flat_destroy(shray_device_flat *flat)
 {
     delete flat;
+    return SHRAY_OK;
+}
+
+// (internal, device_tree_internal.h)
+int shrayi_device_flat_view(const shray_device_flat *flat, ShrayDeviceFlatView *view)
+{
+    if (!flat || !view)
+        return shrayi_fail(SHRAY_ERR_INVALID_ARGUMENT, "device flat is NULL");
+    view->desc = flat->desc;
+    view->index_of = (const int *)flat->index_of.p;
     return SHRAY_OK;
 }
 

@@ -38,9 +38,12 @@ class World:
                 raise RuntimeError("shray_host_triangles failed")
             then = time.perf_counter()
             tree_handle = C.c_void_p()
-            if options is not None:
-                options.struct_size = C.sizeof(N.BvhOptions)
-            N.check(hip.shray_bvh_build_device(tv, nt, vd, nv, 9, C.byref(options) if options is not None else None, C.byref(tree_handle)))
+            if options is None:
+                # the host builder reads BVH_MAX_DEPTH / BVH_LEAF_MAX / SAH_* from the environment (bvh.cpp:60-79): so does this one
+                # (with the defaults the "bit-identical" device tree silently parted from the host's)
+                options = bvh_options_from_environment()
+            options.struct_size = C.sizeof(N.BvhOptions)
+            N.check(hip.shray_bvh_build_device(tv, nt, vd, nv, 9, C.byref(options), C.byref(tree_handle)))
             try:
                 tree, order = N.TreeDesc(), C.POINTER(C.c_int32)()
                 N.check(hip.shray_device_tree_download(tree_handle, C.byref(tree), C.byref(order)))
@@ -102,24 +105,42 @@ class World:
 
 
     def default_view(self) -> N.HostView:
-        view = N.HostView()
-        self._lib.shray_host_default_view(self._handle, C.byref(view))
-        return view
+        return default_view_of(self._handle)
 
     def frame_params(self, width: int, height: int, view: N.HostView | None = None, *, material: int | None = None,
                      diffuse: int | None = None) -> N.FrameParams:
         """Frame block for a width x height frame (reference ray.cpp:648-704).  `material`
         indexes the reference's table: 0 = gold ... 6 = glazed plaster (ray.cpp:54-65)."""
-        if view is None:
-            view = self.default_view()
-        if material is not None:
-            view.which_material = material
-        if diffuse is not None:
-            view.which_diffuse_color = diffuse
-        params = N.FrameParams()
-        if self._lib.shray_host_frame_params(self._handle, C.byref(view), width, height, C.byref(params)) != 0:
-            raise RuntimeError("frame parameter computation failed")
-        return params
+        return frame_params_of(self._handle, width, height, view, material, diffuse)
+
+
+def default_view_of(world_handle) -> N.HostView:
+    """The start-up view (ray.cpp:1077-1088) of a libshray_host world -- loaded with or without its tree."""
+    view = N.HostView()
+    N.load_host().shray_host_default_view(world_handle, C.byref(view))
+    return view
+
+
+def frame_params_of(world_handle, width: int, height: int, view: N.HostView | None = None, material: int | None = None,
+                    diffuse: int | None = None) -> N.FrameParams:
+    if view is None:
+        view = default_view_of(world_handle)
+    if material is not None:
+        view.which_material = material
+    if diffuse is not None:
+        view.which_diffuse_color = diffuse
+    params = N.FrameParams()
+    if N.load_host().shray_host_frame_params(world_handle, C.byref(view), width, height, C.byref(params)) != 0:
+        raise RuntimeError("frame parameter computation failed")
+    return params
+
+
+def bvh_options_from_environment() -> N.BvhOptions:
+    """BVH_MAX_DEPTH / BVH_LEAF_MAX / SAH_CTRAV / SAH_CISEC as the host builder of this process reads them (bvh.cpp:60-79)."""
+    options = N.BvhOptions()
+    if N.load_host().shray_host_bvh_options(C.byref(options)) != 0:
+        raise RuntimeError("shray_host_bvh_options failed")
+    return options
 
 
 def desc_arrays(d) -> dict:

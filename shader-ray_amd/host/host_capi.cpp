@@ -84,6 +84,19 @@ int shray_host_triangles(shray_host_world *world, const int32_t **triangle_verti
     return 0;
 }
 
+int shray_host_bvh_options(shray_bvh_options *options)
+{
+    if (!options)
+        return -1;
+    const bvh_build_options &o = bvh_options();
+    options->struct_size = (uint32_t)sizeof(shray_bvh_options);
+    options->max_depth = o.max_depth;
+    options->leaf_max = (int32_t)o.leaf_max;
+    options->sah_ctrav = o.sah_ctrav;
+    options->sah_cisec = o.sah_cisec;
+    return 0;
+}
+
 int shray_host_adopt_tree(shray_host_world *world, const shray_tree_desc *tree, const int32_t *triangle_order, double build_seconds)
 {
     if (!world || !world->w || !tree || !triangle_order || tree->struct_size != sizeof(shray_tree_desc))

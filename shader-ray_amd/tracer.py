@@ -28,6 +28,31 @@ class Scene:
         if environment is not None:
             self.set_environment(environment)
 
+    @classmethod
+    def from_device(cls, tree_handle, flat_handle, environment: np.ndarray | None = None):
+        """A scene from a tree that never left the device (shray_scene_create_from_device): `tree_handle` from
+        shray_bvh_build_device, `flat_handle` from shray_flatten_device_tree (both may be destroyed afterwards)."""
+        self = cls.__new__(cls)
+        self._lib = N.load_hip()
+        handle = C.c_void_p()
+        N.check(self._lib.shray_scene_create_from_device(tree_handle, flat_handle, C.byref(handle)))
+        self._handle = handle
+        if environment is not None:
+            self.set_environment(environment)
+        return self
+
+    def derived_arrays(self) -> dict:
+        """What scene creation derived, read back (tests): packed_nodes uint32 [8, nodes, 8], packed_tris uint32 [triangles, 9],
+        normals16 uint16 [corners * 3], pair_nodes uint32 [nodes, 16], stack_levels."""
+        a, b, c, d, levels = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        N.check(self._lib.shray_scene_derived_sizes(self._handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(levels)))
+        nodes, tris = np.zeros(a.value // 4, np.uint32), np.zeros(b.value // 4, np.uint32)
+        halves, pairs = np.zeros(c.value // 2, np.uint16), np.zeros(d.value // 4, np.uint32)
+        N.check(self._lib.shray_scene_derived_download(self._handle, nodes.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p),
+                                                       halves.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p)))
+        return {"packed_nodes": nodes.reshape(8, -1, 8), "packed_tris": tris.reshape(-1, 9), "normals16": halves,
+                "pair_nodes": pairs.reshape(-1, 16), "stack_levels": levels.value}
+
     def close(self):
         if getattr(self, "_handle", None):
             self._lib.shray_scene_destroy(self._handle)
@@ -152,6 +177,100 @@ class DeviceFlat:
         if getattr(self, "_handle", None):
             self._lib.shray_device_flat_destroy(self._handle)
             self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceWorld:
+    """File -> resident scene with the BVH, the flattening and everything scene creation derives done ON THE DEVICE (round 6):
+    the host parses the file (libshray_host: load_triangles -- world.cpp:46-134 without make_bvh); shray_bvh_build_device,
+    shray_flatten_device_tree and shray_scene_create_from_device do the rest where the data lies.  No tree is downloaded and no
+    group tree is built on the host unless somebody asks for one (`host_world()`).  `seconds`: the stages' wall times."""
+
+    def __init__(self, filename: str, environment: np.ndarray | None = None, options: "N.BvhOptions | None" = None, device: int | None = None,
+                 data_texture_width: int = 2048, quiet: bool = True):
+        import time
+        from . import host
+        hip, lib = N.load_hip(), N.load_host()
+        lib.shray_host_set_quiet(1 if quiet else 0)
+        if device is not None:
+            N.check(hip.shray_set_device(device))
+        self._hip, self._host, self.filename = hip, lib, filename
+        self.seconds = {}
+        t0 = time.perf_counter()
+        handle = C.c_void_p()
+        if lib.shray_host_load_triangles(filename.encode(), C.byref(handle)) != 0 or not handle:
+            raise RuntimeError(f"load_triangles failed for {filename!r} (see stderr)")
+        self._world_handle = handle
+        tv, vd, nt, nv = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int32(), C.c_int32()
+        if lib.shray_host_triangles(handle, C.byref(tv), C.byref(nt), C.byref(vd), C.byref(nv)) != 0:
+            raise RuntimeError("shray_host_triangles failed")
+        t1 = time.perf_counter()
+        if options is None:
+            options = host.bvh_options_from_environment()
+        options.struct_size = C.sizeof(N.BvhOptions)
+        self._options = options
+        self._tree = C.c_void_p()
+        N.check(hip.shray_bvh_build_device(tv, nt, vd, nv, 9, C.byref(options), C.byref(self._tree)))
+        t2 = time.perf_counter()
+        self._flat = C.c_void_p()
+        N.check(hip.shray_flatten_device_tree(self._tree, data_texture_width, C.byref(self._flat)))
+        t3 = time.perf_counter()
+        self.scene = Scene.from_device(self._tree, self._flat, None)
+        t4 = time.perf_counter()
+        if environment is not None:
+            self.scene.set_environment(environment)
+        stats = N.BvhStats()
+        N.check(hip.shray_device_tree_stats(self._tree, C.byref(stats)))
+        self.stats = stats
+        self.triangle_count = nt.value
+        self.seconds = {"parse": t1 - t0, "bvh": t2 - t1, "bvh_on_the_device": stats.device_seconds, "flatten": t3 - t2, "scene": t4 - t3,
+                        "triangles_to_resident": t4 - t1, "total": t4 - t0}
+        self._adopted = False
+
+    def frame_params(self, width: int, height: int, view=None, material: int | None = None, diffuse: int | None = None):
+        """The frame block (ray.cpp:648-704) -- it needs the mesh's extent, not its tree."""
+        from . import host
+        return host.frame_params_of(self._world_handle, width, height, view, material, diffuse)
+
+    def default_view(self):
+        from . import host
+        return host.default_view_of(self._world_handle)
+
+    def flat_arrays(self) -> dict:
+        """The flattened (reference-layout) arrays, downloaded (tests)."""
+        from .host import desc_arrays
+        desc = N.SceneDesc()
+        N.check(self._hip.shray_device_flat_download(self._flat, C.byref(desc)))
+        return desc_arrays(desc)
+
+    def host_world(self):
+        """The reference's `world` with its group tree (world.h:48-51), built NOW from the device's tree: shray_device_tree_download +
+        shray_host_adopt_tree.  Returns the libshray_host world handle (owned by this object)."""
+        if not self._adopted:
+            tree, order = N.TreeDesc(), C.POINTER(C.c_int32)()
+            N.check(self._hip.shray_device_tree_download(self._tree, C.byref(tree), C.byref(order)))
+            if self._host.shray_host_adopt_tree(self._world_handle, C.byref(tree), order, float(self.seconds.get("bvh", 0.0))) != 0:
+                raise RuntimeError("shray_host_adopt_tree refused the device-built tree")
+            self._adopted = True
+        return self._world_handle
+
+    def close(self):
+        if getattr(self, "scene", None) is not None:
+            self.scene.close()
+            self.scene = None
+        for name, destroy in (("_flat", "shray_device_flat_destroy"), ("_tree", "shray_device_tree_destroy")):
+            h = getattr(self, name, None)
+            if h:
+                getattr(self._hip, destroy)(h)
+                setattr(self, name, None)
+        if getattr(self, "_world_handle", None):
+            self._host.shray_host_free_world(self._world_handle)
+            self._world_handle = None
 
     def __del__(self):
         try:

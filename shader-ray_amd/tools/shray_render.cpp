@@ -13,8 +13,9 @@
 //                              launch), exchanged over xGMI (RCCL) and assembled -- shader_ray_dist.h.
 //                [-r mode]     with -g: root0 (every frame assembled on GPU 0) or rotate (frame f on GPU f % N; default)
 //                [-t name]     with -g: rccl (default) or loopback (all ranks share GPU 0: rehearsal on a one-GPU box)
-//                [-b where]    the BVH: host (make_bvh, bvh.cpp:288-358; default) or gpu (shray_bvh_build_device: the same tree,
-//                              built on the device -- load_triangles, the device build, adopt_tree)
+//                [-b where]    the BVH: host (make_bvh, bvh.cpp:288-358; default), gpu (shray_bvh_build_device: the same tree,
+//                              built on the device -- load_triangles, the device build, adopt_tree) or device (round 6: the build, the
+//                              flattening and scene creation all on the device; no group tree on the host, nothing downloaded)
 //
 // background: "r, g, b" floats, "grid", hex "rrggbb" (ray.cpp:1002-1035) or a Radiance .hdr file
 // (host/background.cpp; the reference decodes image files through FreeImagePlus).
@@ -165,7 +166,55 @@ int main(int argc, char **argv)
     }
 
     world_ptr world;
-    if (bvh_where == "gpu") {
+    shray_scene *resident = nullptr;      // -b device: the scene, made without the tree ever leaving the device
+    double device_pipeline_seconds[3] = {0, 0, 0};
+    if (bvh_where == "device") {
+        // load_world (world.cpp:46-134) + get_shader_data (world.cpp:298-347) + the texture upload (ray.cpp:470-497) with everything
+        // behind the parse on the device: shray_bvh_build_device -> shray_flatten_device_tree -> shray_scene_create_from_device.  The
+        // `world` keeps its triangles, centre and extent (what the frame parameters need) and no group tree.
+        if (gpus > 1) {
+            fprintf(stderr, "-b device renders on one GPU (the ranks of -g N each create their scene from the host arrays)\n");
+            return EXIT_FAILURE;
+        }
+        world = load_triangles(argv[1]);
+        if (world) {
+            const triangle_set &mesh = *world->triangles;
+            std::vector<int32_t> corners(3 * mesh.triangles.size());
+            for (size_t t = 0; t < mesh.triangles.size(); t++)
+                for (int c = 0; c < 3; c++)
+                    corners[3 * t + c] = mesh.triangles[t].i[c];
+            const bvh_build_options &bo = bvh_options();
+            shray_bvh_options options = {sizeof(shray_bvh_options), bo.max_depth, (int32_t)bo.leaf_max, bo.sah_ctrav, bo.sah_cisec};
+            shray_device_tree *built = nullptr;
+            shray_device_flat *flat = nullptr;
+            auto then = std::chrono::steady_clock::now();
+            auto lap = [&then]() {
+                const auto now = std::chrono::steady_clock::now();
+                const double s = std::chrono::duration<double>(now - then).count();
+                then = now;
+                return s;
+            };
+            bool ok = shray_set_device(0) == SHRAY_OK &&
+                      shray_bvh_build_device(corners.data(), (int32_t)mesh.triangles.size(), &mesh.vertices[0].v.x, (int32_t)mesh.vertices.size(), 9,
+                                             &options, &built) == SHRAY_OK;
+            device_pipeline_seconds[0] = lap();
+            ok = ok && shray_flatten_device_tree(built, 2048, &flat) == SHRAY_OK;
+            device_pipeline_seconds[1] = lap();
+            ok = ok && shray_scene_create_from_device(built, flat, &resident) == SHRAY_OK;
+            device_pipeline_seconds[2] = lap();
+            if (!ok) {
+                fprintf(stderr, "The device-resident scene pipeline failed: %s\n", shray_last_error());
+                return EXIT_FAILURE;
+            }
+            shray_bvh_stats stats;
+            shray_device_tree_stats(built, &stats);
+            world->build_seconds = device_pipeline_seconds[0];
+            host_info("BVH: %f seconds (on the GPU: %f; %d nodes, %d leaves, deepest level %d)\n", world->build_seconds, stats.device_seconds,
+                      stats.node_count, stats.leaf_count, stats.max_level);
+            shray_device_flat_destroy(flat);
+            shray_device_tree_destroy(built);
+        }
+    } else if (bvh_where == "gpu") {
         // load_world (world.cpp:46-134) with make_bvh replaced by the device build
         world = load_triangles(argv[1]);
         if (world) {
@@ -209,7 +258,8 @@ int main(int argc, char **argv)
 
     scene_shader_data data;
     const auto flatten_began = std::chrono::steady_clock::now();
-    get_shader_data(world, data, 2048);
+    if (!resident)
+        get_shader_data(world, data, 2048);
     const double flatten_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - flatten_began).count();
     shray_scene_desc desc;
     memset(&desc, 0, sizeof(desc));
@@ -326,10 +376,15 @@ int main(int argc, char **argv)
         frames = 0;   // no per-frame histogram: the loop's rate is printed above
     } else {
         const auto create_began = std::chrono::steady_clock::now();
-        if (shray_scene_create(&desc, &scene) != SHRAY_OK || shray_scene_set_environment(scene, env.data(), env_w, env_h) != SHRAY_OK) {
+        if (resident)
+            scene = resident;
+        if ((!resident && shray_scene_create(&desc, &scene) != SHRAY_OK) || shray_scene_set_environment(scene, env.data(), env_w, env_h) != SHRAY_OK) {
             fprintf(stderr, "GPU setup failed: %s\n", shray_last_error());
             return EXIT_FAILURE;
         }
+        if (resident)
+            fprintf(stderr, "device-resident pipeline: BVH %.4f s, flatten %.4f s, scene %.4f s -- the tree never left the device\n",
+                    device_pipeline_seconds[0], device_pipeline_seconds[1], device_pipeline_seconds[2]);
         // scene turnaround, file to resident scene (what the reference prints piecewise: world.cpp:93-116, ray.cpp:470-510)
         fprintf(stderr, "scene turnaround: parse %.3f s, centre + extent %.3f s, BVH %.3f s, flatten %.3f s, validate + repack + upload "
                 "(with the environment) %.3f s; %d triangles, %d threads\n", world->parse_seconds, world->extent_seconds,

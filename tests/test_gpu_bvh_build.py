@@ -167,15 +167,17 @@ def test_the_device_tree_feeds_the_device_flattener(pkg, gpu):
 
 
 def test_render_tool_with_the_device_built_tree(gpu, tmp_path):
-    """tools/shray_render -b gpu: the reference-shaped main() with make_bvh replaced by the device build writes the same picture."""
+    """tools/shray_render -b gpu / -b device: the reference-shaped main() with make_bvh replaced by the device build -- and, for
+    `device`, get_shader_data and the upload by the device-resident pipeline -- writes the same picture."""
     exe = os.path.join(ROOT, "shader-ray_amd", "tools", "shray_render")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(exe)), "tools"], check=True, stdout=subprocess.DEVNULL)
     model = os.path.join(GOLDEN, "quads_nonormals.obj")
     pictures = []
-    for where in ("host", "gpu"):
+    for where in ("host", "gpu", "device"):     # device: build, flattening and scene creation on the device, nothing downloaded (round 6)
         out = str(tmp_path / f"{where}.ppm")
         run = subprocess.run([exe, model, "grid", "-o", out, "-w", "96", "-h", "64", "-m", "6", "-b", where], capture_output=True, text=True)
         assert run.returncode == 0, run.stderr[-2000:]
         pictures.append(open(out, "rb").read())
-    assert len(pictures[0]) > 96 * 64 * 3 and pictures[0] == pictures[1]
+        assert ("the tree never left the device" in run.stderr) == (where == "device")
+    assert len(pictures[0]) > 96 * 64 * 3 and pictures[0] == pictures[1] == pictures[2]

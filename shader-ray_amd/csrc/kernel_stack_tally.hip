@@ -3,6 +3,7 @@
 // kernel_stack.hip, which reproduce the reference's full traversals; never timed), and kernel id 3, the pair traversal
 // (both children of a node per turn, wave_traversal.h: inner_stage_pair), timed and tallying.
 #include "kernel_stack_common.h"
+#include "variants/pair_traversal.h"   // the pair instances (kernel id 3) live in this translation unit only
 
 namespace shray {
 

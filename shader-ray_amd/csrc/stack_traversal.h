@@ -107,7 +107,7 @@ struct StackTraversal {
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
             const int alive = __popcll(wave_ballot(state != LT_ENDED));
             const int keep = max(SHRAY_KEEP_FLOOR, (alive * ((DEAL && CONVERGED) ? kStackKeepWalkingDealt : kStackKeepWalking) + 32) >> 6);
-            if (PAIR) {
+            if constexpr (PAIR) {        // (variants/pair_traversal.h: kernel id 3's translation unit includes it)
                 inner_stage_pair<COUNT, BLOCK>(sc, t, state, stack, rc, keep);
                 retest_stage<COUNT, BLOCK>(sc, t, state, stack, rc);
             } else {

@@ -51,86 +51,33 @@ __device__ __forceinline__ V3 unit_of_eye(V3 a, bool components_in_range)
     return mk(div_by_constant4(a.x, length, y, yl), div_by_constant4(a.y, length, y, yl), div_by_constant4(a.z, length, y, yl));
 }
 
-// PARK (kernel_stack_common.h: parks_state): the words of the sample loop that are only touched BETWEEN traversals live in the
-// wave's LDS slab `park` instead of in registers -- [lane][4] = {x, y, z of the running product `modulation` (zero diffuse colour) or
-// of `accumulated` (with a diffuse term), the lane's channel sum}, and with a diffuse term one more row [lane] for the second
-// channel sum.  A lane reads and writes its own words only; every read sits behind a compiler barrier (the traversal in between
-// writes LDS through other pointers).
-typedef float parked_f3 __attribute__((ext_vector_type(3)));
+// The sample loop's `accumulated`, `modulation` and channel sums between traversals: registers.  (-DSHRAY_PARK=1 keeps them in the
+// wave's spare LDS instead -- variants/parked_state.h: built, bit-identical, 1 % slower, R5.2 -- behind the same interface.)
+#ifndef SHRAY_PARK
+#define SHRAY_PARK 0
+#endif
+#if SHRAY_PARK
+}   // namespace shray
+#include "variants/parked_state.h"
+namespace shray {
+#else
 template <bool PARK, bool METAL>
 struct ParkedState {
-    float *slab;                       // this lane's four words (PARK only)
-    V3 product = mk(1, 1, 1), sum = mk(0, 0, 0);   // modulation, accumulated: whichever is not parked -- or both
+    static_assert(!PARK, "the parked form is variants/parked_state.h (-DSHRAY_PARK=1)");
+    float *slab;                                   // (the parked form's; kept so that both forms lay their members out alike)
+    V3 product = mk(1, 1, 1), sum = mk(0, 0, 0);   // modulation, accumulated
     float channel = 0.0f, channel2 = 0.0f;
-    __device__ __forceinline__ void begin(float *park)
-    {
-        slab = PARK ? park + 4u * (threadIdx.x & 63u) : nullptr;
-        if (PARK) {
-            slab[3] = 0.0f;
-            if (!METAL)
-                park[256u + (threadIdx.x & 63u)] = 0.0f;
-        }
-    }
-    __device__ __forceinline__ float *second(float *) const { return slab - 4u * (threadIdx.x & 63u) + 256u + (threadIdx.x & 63u); }
-    __device__ __forceinline__ V3 read3() const
-    {
-        asm volatile("" ::: "memory");
-        const parked_f3 v = *reinterpret_cast<const parked_f3 *>(slab);
-        return mk(v.x, v.y, v.z);
-    }
-    __device__ __forceinline__ void write3(V3 v) const
-    {
-        parked_f3 w;
-        w.x = v.x;
-        w.y = v.y;
-        w.z = v.z;
-        *reinterpret_cast<parked_f3 *>(slab) = w;
-    }
-    __device__ __forceinline__ V3 modulation() const { return (PARK && METAL) ? read3() : product; }
-    __device__ __forceinline__ void set_modulation(V3 v)
-    {
-        if (PARK && METAL)
-            write3(v);
-        else
-            product = v;
-    }
-    __device__ __forceinline__ V3 accumulated() const { return (PARK && !METAL) ? read3() : sum; }
-    __device__ __forceinline__ void set_accumulated(V3 v)
-    {
-        if (PARK && !METAL)
-            write3(v);
-        else
-            sum = v;
-    }
-    __device__ __forceinline__ float channel_sum() const
-    {
-        if (!PARK)
-            return channel;
-        asm volatile("" ::: "memory");
-        return slab[3];
-    }
-    __device__ __forceinline__ void set_channel_sum(float v)
-    {
-        if (PARK)
-            slab[3] = v;
-        else
-            channel = v;
-    }
-    __device__ __forceinline__ float channel_sum2() const
-    {
-        if (!(PARK && !METAL))
-            return channel2;
-        asm volatile("" ::: "memory");
-        return *second(nullptr);
-    }
-    __device__ __forceinline__ void set_channel_sum2(float v)
-    {
-        if (PARK && !METAL)
-            *second(nullptr) = v;
-        else
-            channel2 = v;
-    }
+    __device__ __forceinline__ void begin(float *) { slab = nullptr; }
+    __device__ __forceinline__ V3 modulation() const { return product; }
+    __device__ __forceinline__ void set_modulation(V3 v) { product = v; }
+    __device__ __forceinline__ V3 accumulated() const { return sum; }
+    __device__ __forceinline__ void set_accumulated(V3 v) { sum = v; }
+    __device__ __forceinline__ float channel_sum() const { return channel; }
+    __device__ __forceinline__ void set_channel_sum(float v) { channel = v; }
+    __device__ __forceinline__ float channel_sum2() const { return channel2; }
+    __device__ __forceinline__ void set_channel_sum2(float v) { channel2 = v; }
 };
+#endif
 
 template <class Traversal, bool COUNT, bool ONE_SAMPLE, bool METAL, bool TIMED_FORM = false, bool ORDERED = false, bool PARK = false>
 __device__ __forceinline__ void trace_pixels_uniform(const SceneView &sc, const FrameView &fr, float4 *__restrict__ out,

@@ -21,6 +21,17 @@
 // Arithmetic, visit order and iteration counting are exactly those of stack_traversal.h's
 // first version and of the literal threaded kernel; tests require bit-identical frames and
 // equal work counters across all of them.
+//
+// Where things are (round 6: this file was 1,200 lines, two fifths of them variants that are off):
+//   wave_traversal.h   (this file) a lane's traversal state, ONE NODE VISIT as the compiler writes it (lane_visit_loaded: the
+//                      counting twins, and the rare turns the scheduled stage hands back), the node stage inner_stage
+//   visit_asm.h        the node stage of the timed instances, hand-scheduled: what the shipped kernels run
+//   leaf_stage.h       triangle_intersect, the sequential leaf loop, the dealt leaf stage (compiler's form)
+//   leaf_asm.h         the leaf loops of the timed instances, hand-scheduled: what the shipped kernels run
+//   leaf_cache.h       north_star's LDS staging of leaf triangles (libshray_hip_leafcache.so; measured slower, R5.1)
+//   variants/          what was built, measured and is off: pair_traversal.h (kernel id 3), packed_slab.h (-DSHRAY_PK_SLAB),
+//                      parked_state.h (-DSHRAY_PARK), diagnostics.h + *.inc (-DSHRAY_DIAGNOSTICS)
+// The shipped instances' ISA is the same instruction for instruction before and after the split (profiles/r06/prune_isa_identity.txt).
 #pragma once
 
 #include "exact_div.h"
@@ -43,32 +54,9 @@ enum : int { LT_WALK = 1, LT_LEAF = 2, LT_ENDED = 3, LT_RETEST = 4 };
 #define SHRAY_NODE_TURNS 4
 #endif
 
-// Diagnostic build only: wave-level tallies {node-loop iterations, leaf-loop iterations,
-// cycles in the node loop, cycles in the leaf loop}, read by profiles/timeline.py.
-
-// SHRAY_DIAG_KHIST (with SHRAY_DIAGNOSTICS; profiles/leaf_stage_histogram.py): the eight tallies are instead a histogram of
-// the dealt leaf stages by the number of parked lanes K -- bins K = 1, 2, 3-4, 5-8, 9-16, 17-32, > 32 (the plain loop) --,
-// each word {stages, bits 0-23; rounds of three strided fetches the stage runs, bits 24-43; 16-byte-per-lane fetches a
-// stage would run if every group fetched its leaf's bytes as consecutive chunks, bits 44-63}; nothing is timed.
-#if defined(SHRAY_DIAGNOSTICS) && defined(SHRAY_DIAG_KHIST)
-#ifndef SHRAY_DIAG_KHIST_FROM
-#define SHRAY_DIAG_KHIST_FROM 32
-#endif
-#define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SHRAY_DIAG_T0
-#define SHRAY_DIAG_WAIT(k) ((void)0)
-#define SHRAY_DIAG_COUNT(k) ((void)0)
-#define SHRAY_DIAG_PARAM , unsigned long long *diag_tally_ref
-#define SHRAY_DIAG_ARG , diag_tally
-#define SHRAY_DIAG_ARG_FWD , diag_tally_ref
-#elif defined(SHRAY_DIAGNOSTICS)
-#define SHRAY_DIAG_DECL unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SHRAY_DIAG_T0 const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
-#define SHRAY_DIAG_WAIT(k) do { __builtin_amdgcn_s_waitcnt(0); diag_tally_ref[k] += __builtin_amdgcn_s_memtime() - diag_t0; } while (0)
-#define SHRAY_DIAG_COUNT(k) (diag_tally_ref[k]++)
-#define SHRAY_DIAG_PARAM , unsigned long long *diag_tally_ref
-#define SHRAY_DIAG_ARG , diag_tally
-#define SHRAY_DIAG_ARG_FWD , diag_tally_ref
+// (the diagnostic build threads wave-level tallies through the stages: variants/diagnostics.h; empty here)
+#ifdef SHRAY_DIAGNOSTICS
+#include "variants/diagnostics.h"
 #else
 #define SHRAY_DIAG_DECL
 #define SHRAY_DIAG_T0
@@ -288,40 +276,21 @@ constexpr float kCheckUp = 1.0f + 0x1p-19f, kCheckDown = 1.0f - 0x1p-19f;     //
 // (r1 comes back WITHOUT its clamp to kRangeMax: the visit folds the clamp into its three-operand minimum with hit.t, a leaf
 // that is entered applies it to what it parks)
 // (lo = the entry planes, hi = the exit planes of the ray's octant: no select)
-// Round 5 (R5.7), built, bit-identical, SLOWER, off (-DSHRAY_PK_SLAB=1): the six subtractions and six multiplications as six PACKED
-// fp32 instructions (v_pk_add_f32 with its second source negated, v_pk_mul_f32: IEEE per component, the same values), on register
-// PAIRS -- { entry.x, entry.y }, { exit.x, exit.y }, { entry.z, exit.z } as the record's loads leave them (DeviceNode), { P.x, P.y },
-// { Y.x, Y.y } and { P.z, Y.z } of the ray, the z pair serving both halves of its instructions through op_sel; no pairing moves in
-// the ISA.  Six issue slots fewer per visit -- and the headline 1 % slower, configs 3 / 5 2.3 % (profiles/r05/packed_slab_ab.txt):
-// a packed instruction occupies the VALU as long as the two it replaces (R4.16) and its results arrive later in the visit's
-// dependent chain (subtract -> multiply -> max3 -> compare).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (-DSHRAY_PK_SLAB=1, variants/packed_slab.h: the same twelve operations as six packed instructions; bit-identical, slower, R5.7)
 #ifndef SHRAY_PK_SLAB
 #define SHRAY_PK_SLAB 0
 #endif
+#if SHRAY_PK_SLAB
+#include "variants/packed_slab.h"
+#else
 __device__ __forceinline__ void slab_range_fast(const LaneTraversal &t, const float4 lo, const float4 hi, float &r0, float &r1)
 {
-#if SHRAY_PK_SLAB
-    f32x2 e = {lo.x, lo.y}, x = {hi.x, hi.y}, z = {lo.z, hi.z};
-    const f32x2 pxy = {t.P.x, t.P.y}, yxy = {t.Y.x, t.Y.y}, pzyz = {t.P.z, t.Y.z};
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e) : "v"(e), "v"(pxy));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(pxy));
-    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(z) : "v"(z), "v"(pzyz));
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(yxy));
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(yxy));
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(z) : "v"(z), "v"(pzyz));
-    // (a bare v_max_f32: fmaxf() of an asm result is canonicalised first -- one more instruction)
-    float first;
-    asm("v_max_f32_e32 %0, 0, %1" : "=v"(first) : "v"(e.x));
-    r0 = fmaxf(fmaxf(first, e.y), z.x);
-    r1 = fminf(fminf(x.x, x.y), z.y);
-#else
     const float ex = lo.x - t.P.x, ey = lo.y - t.P.y, ez = lo.z - t.P.z;
     const float xx = hi.x - t.P.x, xy = hi.y - t.P.y, xz = hi.z - t.P.z;
     r0 = fmaxf(fmaxf(fmaxf(0.0f, ex * t.Y.x), ey * t.Y.y), ez * t.Y.z);
     r1 = fminf(fminf(xx * t.Y.x, xy * t.Y.y), xz * t.Y.z);
-#endif
 }
+#endif
 
 // The leaf's exact clipped range (fs:406: the range the leaf's box test left), from the leaf's own record: t.node is
 // still the leaf while a lane is parked (not in the pair traversal, which parks exact ranges and never asks).
@@ -427,122 +396,6 @@ __device__ __forceinline__ int lane_visit_loaded(const FrameView &fr, LaneTraver
     return lane_advance<BLOCK>(t, stack, false, 0u);
 }
 
-// 1 / det of triangle_intersect (fs:314).  A determinant the shader goes on with is at least 1e-7 (its early-out, fs:312);
-// below 2^100 (every scene of finite size) the three-instruction reciprocal of exact_div.h IS the correctly rounded
-// quotient; a larger one, or NaN, takes the true division (the wave skips it).  (triangle_candidate applies the early-out
-// after the arithmetic -- a conjunction --: what this returns for a determinant below 1e-7 is never looked at.)
-__device__ __forceinline__ float reciprocal_of_determinant(float det)
-{
-    float inv = reciprocal_in_range(det);
-#ifdef SHRAY_COST_MAIN_PATH     // profiles/isa_costs.hip counts the path every wave takes, not the division the rare one adds
-    return inv;
-#endif
-    const bool large = !(fabsf(det) < 0x1p100f);
-    if (__builtin_expect(wave_ballot(large) != 0ull, 0)) {
-        asm volatile("; determinant outside the reciprocal's domain" ::: "memory");   // keeps this a branch
-        if (large)
-            inv = 1.0f / det;
-    }
-    return inv;
-}
-
-// triangle_intersect (fs:297-346) in its two halves (profiles/isa_costs.py counts each in isolation).
-// First half, fs:307-331: determinant, distance, the early-outs against the determinant's epsilon, the closest hit so
-// far and the leaf's clipped range.  Returns false where the shader returns.
-struct TriangleSetup {
-    V3 M, T, Q;
-    float inv_det, dist;
-};
-__device__ __forceinline__ bool triangle_distance(const LaneTraversal &t, const float4 q0, const float4 q1, const float4 q2,
-                                                  TriangleSetup &s)
-{
-    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
-    s.M = cross3(e1, t.D);
-    const float det = dot3(e0, s.M);
-    if (det > -0.0000001f && det < 0.0000001f)
-        return false;
-    s.inv_det = reciprocal_of_determinant(det);
-    s.T = t.P - v0;
-    s.Q = cross3(s.T, e0);
-    s.dist = -dot3(e1, s.Q) * s.inv_det;
-    // `d > hit.t || d > r1` is `d > min(hit.t, r1)` whatever is NaN (the hardware minimum returns the other operand, and a
-    // comparison with NaN is false either way); the compiler makes the same fold but canonicalises both operands first
-    // (two v_max x, x per test).  One bare v_min_f32:
-    float upper;
-    asm("v_min_f32 %0, %1, %2" : "=v"(upper) : "v"(t.hit.t), "v"(t.leaf_r1));
-    return !(s.dist > upper || s.dist < t.leaf_r0);
-}
-// Second half, fs:333-346: the barycentric tests and the store.
-// BOUNDS: the lane parked bounds of its leaf's range, not the range (lane_visit_loaded): a candidate that has passed
-// everything else and lies within 2^-19 of an end is held against the exact range before it is stored.
-template <bool BOUNDS>
-__device__ __forceinline__ void triangle_barycentrics(const SceneView &sc, LaneTraversal &t, uint32_t which, const TriangleSetup &s)
-{
-    const float u = dot3(s.T, s.M) * s.inv_det;
-    if (u < 0.0f || u > 1.0f)
-        return;
-    const float w = dot3(t.D, s.Q) * s.inv_det;
-    if (w < 0.0f || u + w > 1.0f)
-        return;
-    if (BOUNDS) {
-        const bool near_end = near_range_end(s.dist, t.leaf_r0, t.leaf_r1);
-        if (__builtin_expect(wave_ballot(near_end) != 0ull, 0)) {
-            asm volatile("; a candidate at an end of its leaf's range: the exact range" ::: "memory");   // keeps this a branch
-            if (near_end) {
-                float e0, e1;
-                exact_leaf_range(sc, t, e0, e1);
-                if (s.dist < e0 || s.dist > e1)
-                    return;                       // fs:329-331
-            }
-        }
-    }
-    t.hit.which = (float)which;
-    t.hit.t = s.dist;
-    t.hit.bu = u;
-    t.hit.bv = w;
-}
-
-// triangle_intersect of triangle `which` (its three 16-byte words) for a parked lane
-template <bool COUNT, bool BOUNDS>
-__device__ __forceinline__ void lane_test_triangle_loaded(const SceneView &sc, LaneTraversal &t, uint32_t which, RayCounters &rc,
-                                                          const float4 q0, const float4 q1, const float4 q2)
-{
-    if (COUNT)
-        rc.triangle_tests++;
-    TriangleSetup s;
-    if (triangle_distance(t, q0, q1, q2, s))
-        triangle_barycentrics<BOUNDS>(sc, t, which, s);
-}
-
-// The nine floats of a packed triangle, fetched as three 12-byte loads issued back to back and handed on as the
-// three words {v0, e0.x} {e0.yz, e1.xy} {e1.z} the tests unpack.  (Left to itself the compiler splits the loads and
-// sinks part of them behind the `det` early-out of the test, which costs a second dependent memory round trip per
-// triangle: hence the pin below.)
-struct PackedF3 {
-    float x, y, z;
-};
-__device__ __forceinline__ void load_packed_triangle_at(const SceneView &sc, uint32_t byte_offset, float4 &q0, float4 &q1, float4 &q2);
-__device__ __forceinline__ void load_packed_triangle(const SceneView &sc, uint32_t index, float4 &q0, float4 &q1, float4 &q2)
-{
-    load_packed_triangle_at(sc, index * 36u, q0, q1, q2);
-}
-__device__ __forceinline__ void load_packed_triangle_at(const SceneView &sc, uint32_t byte_offset, float4 &q0, float4 &q1, float4 &q2)
-{
-    // base + 32-bit byte offset, as for the nodes
-    // 36 bytes as 16 + 16 + 4 (what the back end makes of three 12-byte loads anyway), pinned as the register tuples the
-    // loads fill: pinned component by component, every test began with five or six moves out of those tuples
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef f4 __attribute__((aligned(4), may_alias)) packed_f4;
-    const char *p = reinterpret_cast<const char *>(sc.packed_tris) + byte_offset;
-    f4 a = *reinterpret_cast<const packed_f4 *>(p), b = *reinterpret_cast<const packed_f4 *>(p + 16);
-    float c = *reinterpret_cast<const float *>(p + 32);
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-    q0 = make_float4(a.x, a.y, a.z, a.w);
-    q1 = make_float4(b.x, b.y, b.z, b.w);
-    q2 = make_float4(c, 0.0f, 0.0f, 0.0f);
-}
-
-
 // Node loop: lanes whose state is LT_WALK visit nodes until fewer than `keep_walking` of
 // them remain while other lanes are parked (state == LT_LEAF) or `others_waiting`.
 // The iteration cap: the counting instances (COUNT: the reference's tallies AND the timed form's tallying twins, TALLY == 1)
@@ -580,646 +433,6 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
     }
 }
 
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ int lane_pop(const SceneView &sc, LaneTraversal &t, uint32_t *stack, RayCounters &rc);
-
-// triangles a parked lane tests: its leaf's count (the flag bit may still be on it), at most max_leaf_tests (fs:411)
-__device__ __forceinline__ uint32_t parked_count(uint32_t leaf_count, uint32_t leaf_cap) { return min(leaf_count & ~kLeafFlag, leaf_cap); }
-
-// Leaf stage: every parked lane tests its leaf's triangles in order, then follows its link.
-// PAIR: the lane belongs to the pair traversal (below): "follow the link" is lane_pop.
-// its loop (some lane must be parked) ...
-template <bool COUNT, bool BOUNDS>
-__device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
-{
-#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
-    {   // how much a triangle-parallel leaf stage could save: stages, and 64-wide rounds over all parked triangles
-        unsigned int total = (state == LT_LEAF) ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
-        for (int off = 32; off > 0; off >>= 1)
-            total += __shfl_xor(total, off, 64);
-        diag_tally_ref[6] += 1;
-        diag_tally_ref[7] += (total + 63u) / 64u;
-    }
-#endif
-    // a lane that is not parked has no triangles: ONE comparison per round decides both who works and whether anyone does
-    // (as `state == LT_LEAF && j < count` the wave-level test cost a select and a second comparison per round; the pin
-    // keeps the compiler from turning it back into that)
-    uint32_t mine = state == LT_LEAF ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
-    asm volatile("" : "+v"(mine));
-    // bottom-tested: some lane is parked, and a parked lane has at least one triangle (a top-tested loop over a wave-level
-    // condition is not rotated by the compiler, and then carries the hit's four fields in two register sets with a copy at
-    // every level of the test's early-outs)
-    uint32_t j = 0;
-    do {
-        SHRAY_DIAG_COUNT(1);
-        if (j < mine) {
-            float4 q0, q1, q2;
-            SHRAY_DIAG_T0
-            load_packed_triangle(sc, t.leaf_first + j, q0, q1, q2);
-            SHRAY_DIAG_WAIT(5);
-            lane_test_triangle_loaded<COUNT, BOUNDS>(sc, t, t.leaf_first + j, rc, q0, q1, q2);
-        }
-        j++;
-    } while (wave_ballot(j < mine));
-}
-
-// The same loop for the timed instances as one hand-scheduled statement (leaf_asm.h, included at the end of this file); the
-// counting twins, the pair traversal (exact parked ranges) and the diagnostic build keep the compiler's form.
-#ifndef SHRAY_ASM_LEAF
-#define SHRAY_ASM_LEAF 1
-#endif
-__device__ __forceinline__ void leaf_loop_scheduled(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc);
-__device__ __forceinline__ bool dealt_rounds_scheduled(const SceneView &sc, const LaneTraversal &t, int source, uint32_t end, uint32_t G,
-                                                       uint32_t tri, uint32_t where, float &best_d, float &best_u, float &best_w, uint32_t &best);
-template <bool COUNT, bool BOUNDS>
-__device__ __forceinline__ void leaf_loop_timed_or_counted(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
-{
-#if SHRAY_ASM_LEAF && !defined(SHRAY_DIAGNOSTICS)
-    if (!COUNT && BOUNDS) {
-        leaf_loop_scheduled(sc, t, state, rc);
-        return;
-    }
-#endif
-    leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
-}
-
-// Leaf cache (round 5).  The lanes of a wave that are parked TOGETHER mostly sit in the same few leaves: the rays of an 8x8
-// tile reach a leaf side by side.  Stages with more than 32 parked lanes, the plain loop's share of the throughput form:
-// ONE distinct leaf in 51 % of them, two in 31 %, three in 11 %, at most four in 96 % (1M-triangle scene: 15 / 28 / 25 %,
-// at most four in 84 %; profiles/r05/leaf_stage_histograms.txt) -- and those stages are 71 % of all triangle rounds.
-// The plain loop fetched every lane's triangle in every round: three strided fetches (16 + 16 + 4 bytes per lane) per
-// round on the CU's one vector memory pipeline, which charges an instruction by its width, not by what its lanes read
-// (DESIGN.md section 5).  Here a stage first names the distinct leaves among its parked lanes (a scalar loop: the first
-// parked lane's leaf, a ballot of the lanes in the same one, the next ...), and each distinct leaf -- 36 x count
-// consecutive bytes of packed_tris -- is fetched ONCE, as consecutive 16-byte chunks by the wave's first lanes, straight
-// into a slot of the wave's slab in LDS (global_load_lds_dwordx4: no registers, nothing waits until the slots are read).
-// Every parked lane then runs its triangles in order, as before, reading them from its leaf's slot: a round is five LDS
-// reads, no fetch.  The lanes of leaves beyond the slab's kCacheSlots fetch their own triangles, as before, in the same rounds.
-// (A leaf has at most kCacheTriangles triangles when the frame's leaf cap is that low -- the shader's is 10 -- else the
-// uncached loop runs.)
-#ifndef SHRAY_LEAF_CACHE
-#define SHRAY_LEAF_CACHE 0                // measured slower (profiles/EXPERIMENTS.md R5.1): built as a variant library only
-#endif
-#ifndef SHRAY_LEAF_CACHE_SLOTS
-#define SHRAY_LEAF_CACHE_SLOTS 3
-#endif
-#ifndef SHRAY_LEAF_CACHE_DEALT
-#define SHRAY_LEAF_CACHE_DEALT 1          // the dealt stage's workers read cached leaves too
-#endif
-constexpr int kCacheSlots = SHRAY_LEAF_CACHE_SLOTS;
-constexpr uint32_t kCacheTriangles = 10;                         // 90 words = 23 chunks of 16 bytes
-constexpr uint32_t kCacheSlotBytes = 400;                        // 368 used; 100 words: consecutive slots start 4 banks apart
-constexpr uint32_t kCacheBytes = (uint32_t)kCacheSlots * kCacheSlotBytes;
-constexpr uint32_t kIdsBytes = 64;                               // the wave's `ids` table in front of its slab
-typedef __attribute__((address_space(1))) const void cache_global_ptr;
-typedef __attribute__((address_space(3))) void cache_lds_ptr;
-
-// One pass of the cache's fill: the first kCacheSlots distinct leaves among the lanes in `todo` (parked, not yet served) are
-// fetched into the slots; `now` = the lanes they serve (taken out of `todo`), `at` = a served lane's slot as a byte offset
-// into the slab.  Nothing waits: the fetches are in flight when this returns (leaf_cache_wait).
-__device__ __forceinline__ void leaf_cache_fill(const SceneView &sc, const LaneTraversal &t, bool &todo, bool &now, uint32_t &at, char *cache)
-{
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const char *tris = reinterpret_cast<const char *>(sc.packed_tris);
-    unsigned long long left = wave_ballot(todo);
-    now = false;
-    at = 0;
-#pragma unroll
-    for (int n = 0; n < kCacheSlots; n++) {
-        if (left != 0ull) {             // (uniform)
-            const int lead = __builtin_ctzll(left);
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)t.leaf_first, lead);
-            const uint32_t count = parked_count((uint32_t)__builtin_amdgcn_readlane((int)t.leaf_count, lead), t.leaf_cap);
-            const bool same = todo && t.leaf_first == first;      // (one leaf, one record: the same count)
-            left &= ~wave_ballot(same);
-            if (same)
-                at = (uint32_t)n;   // (the slot's number: an inline constant; its byte offset below)
-            now = now || same;
-            todo = todo && !same;
-            // whatever lies behind the leaf's last word comes along (the array ends in a spare record, capi.hip) and is
-            // never read back
-            const uint32_t chunks = (count << 1) + ((count + 3u) >> 2);   // ceil(9 count / 4)
-            if (lane < chunks)
-                __builtin_amdgcn_global_load_lds((cache_global_ptr *)(tris + (size_t)(first * 36u) + (lane << 4)),
-                                                 (cache_lds_ptr *)(cache + (uint32_t)n * kCacheSlotBytes), 16, 0, 0);
-        }
-    }
-    at = __umul24(at, kCacheSlotBytes);
-}
-// The slots are read by other lanes than wrote them: the fetches have landed (their counter says so), and the compiler keeps
-// the reads behind this point.  (`pin`: any value the reads' addresses depend on.)
-__device__ __forceinline__ void leaf_cache_wait(uint32_t &pin) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin) : : "memory"); }
-
-// a triangle's nine words from a slot (five LDS reads), as the three words the tests unpack
-__device__ __forceinline__ void load_cached_triangle(const char *p, float4 &q0, float4 &q1, float4 &q2)
-{
-    const float *q = reinterpret_cast<const float *>(p);
-    float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7], a8 = q[8];
-    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
-    q0 = make_float4(a0, a1, a2, a3);
-    q1 = make_float4(a4, a5, a6, a7);
-    q2 = make_float4(a8, 0.0f, 0.0f, 0.0f);
-}
-
-// The sequential loop over a stage whose first kCacheSlots distinct leaves come through the cache: a lane whose leaf has a
-// slot reads its triangles from there, a lane whose leaf has none (a stage with more distinct leaves: the divergent waves,
-// the ones a lone frame waits for) fetches them itself as before -- in the same rounds.
-template <bool COUNT, bool BOUNDS>
-__device__ __forceinline__ void leaf_loop_cached(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc, char *cache SHRAY_DIAG_PARAM)
-{
-    bool todo = state == LT_LEAF, served;
-    uint32_t where;                         // the lane's next triangle: a byte offset into the slab (served) or into packed_tris
-    leaf_cache_fill(sc, t, todo, served, where, cache);
-    if (!served)
-        where = __umul24(t.leaf_first, 36u);
-    uint32_t mine = state == LT_LEAF ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
-    leaf_cache_wait(mine);
-    uint32_t j = 0;
-    do {
-        SHRAY_DIAG_COUNT(1);
-        if (j < mine) {
-            float4 q0, q1, q2;
-            if (served)
-                load_cached_triangle(cache + where, q0, q1, q2);
-            else
-                load_packed_triangle_at(sc, where, q0, q1, q2);
-            lane_test_triangle_loaded<COUNT, BOUNDS>(sc, t, t.leaf_first + j, rc, q0, q1, q2);
-        }
-        j++;
-        where += 36u;
-    } while (wave_ballot(j < mine));
-}
-
-// ... and its end: the parked lanes move on (fs:416-433)
-template <bool COUNT, int BLOCK, bool PAIR>
-__device__ __forceinline__ void leaf_finish(const SceneView &sc, LaneTraversal &t, int &state, uint32_t *stack, RayCounters &rc)
-{
-    if (PAIR) {
-        if (state == LT_LEAF)
-            state = lane_pop<COUNT, BLOCK>(sc, t, stack, rc);
-        return;
-    }
-    // a hit distance that is NaN (an unordered candidate was accepted, see leaf_stage_dealt) fails `r0 < hit.t` at every
-    // later visit; the visit's fast test does not look for it: such a lane takes the exact branch from here on
-    {
-        const unsigned long long no_distance = wave_ballot(state == LT_LEAF && t.hit.t != t.hit.t);
-        if (__builtin_expect(no_distance != 0ull, 0)) {
-            asm volatile("; a hit distance that is NaN" ::: "memory");   // keeps this a branch
-            if (state == LT_LEAF && t.hit.t != t.hit.t)
-                t.divide = true;
-            t.divide_mask |= no_distance;
-        }
-    }
-    if (state == LT_LEAF)
-        state = lane_advance<BLOCK>(t, stack, false, 0u);
-}
-
-// CACHE: `ids` is followed by the wave's leaf cache (above)
-template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false>
-__device__ __forceinline__ void leaf_stage(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                           uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
-{
-    if (!wave_ballot(state == LT_LEAF))
-        return;
-    if (CACHE && t.leaf_cap <= kCacheTriangles)     // (uniform)
-        leaf_loop_cached<COUNT, !PAIR>(sc, t, state, rc, reinterpret_cast<char *>(ids) + kIdsBytes SHRAY_DIAG_ARG_FWD);
-    else
-        leaf_loop_timed_or_counted<COUNT, !PAIR>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
-    leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Dealt leaf stage.  The plain stage above takes max(count) turns whoever is parked: one lane sitting in a
-// 10-triangle leaf costs ten dependent fetch-and-test rounds with one lane active (the normal case in
-// divergent waves: on the 1M-triangle scene the leaf loop runs at 24 % of its lanes, oracle/tools/wave_sim.py).
-// Here the wave's idle lanes do the work: with K <= 32 lanes parked, each parked ray gets a group of
-// G = 2, 4, 8 or 16 worker lanes (G * K <= 64); worker i of a group pulls the ray (ds_bpermute) and tests
-// triangles i, i + G, ... of its leaf, so the stage takes ceil(count / G) rounds -- one memory round trip
-// instead of up to ten when few lanes are parked.
-//
-// Exactness: triangle_intersect's outcome for one triangle depends on hit.t only through the early-out
-// `d > hit.t` (fs:327); every other test is a pure function of (ray, triangle, leaf range).  Testing the
-// leaf's triangles in order therefore ends with: among the candidates that pass those tests and have
-// d <= the hit.t the leaf started with, the smallest d, and of equal d the LAST in order (equal d
-// overwrites, the test is `>`).  Each worker keeps that rule over its own increasing j, the group combines
-// by (smaller d, then larger j), the parked lane applies the winner.  Same arithmetic on the same values:
-// bit-identical hits; the counting twin tallies the same triangle tests (in the worker lanes).
-//
-// That argument needs the candidates' d to be ORDERED.  A candidate whose d is NaN (a triangle so large that its
-// determinant overflows to inf - inf, or a ray that already carries NaNs) fails none of the shader's comparisons:
-// the sequential loop accepts it, and after it accepts whatever candidate comes next -- an order-dependent
-// outcome no (d, j) ranking reproduces.  A worker that accepts an unordered d raises a flag; if any lane of the
-// wave did, the stage discards the dealt result and runs the plain sequential loop over the untouched parked
-// rays (tests/test_gpu_parity.py::test_nan_candidates_in_a_dealt_leaf).
-#ifndef SHRAY_DEAL_MAX_PARKED
-#define SHRAY_DEAL_MAX_PARKED 32   // at most 32: a group is at least two lanes
-#endif
-
-__device__ __forceinline__ float lane_pull(int src_lane, float v)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-__device__ __forceinline__ int lane_pull(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-
-// triangle_intersect without the store and without the `d > hit.t` early-out, for a ray held in plain values
-// (the worker's copy of another lane's ray): the candidate (dist, u, w) and whether it passes every other early-out of
-// fs:312-340 (a conjunction, so their order does not matter; NaN operands fail the same comparisons as upstream)
-__device__ __forceinline__ bool triangle_candidate(V3 P, V3 D, float r0, float r1, const float4 q0, const float4 q1,
-                                                   const float4 q2, float &dist, float &u, float &w)
-{
-    const V3 v0 = mk(q0.x, q0.y, q0.z), e0 = mk(q0.w, q1.x, q1.y), e1 = mk(q1.z, q1.w, q2.x);
-    const V3 M = cross3(e1, D);
-    const float det = dot3(e0, M);
-    const float inv_det = reciprocal_of_determinant(det);
-    const V3 T = P - v0;
-    const V3 Q = cross3(T, e0);
-    dist = -dot3(e1, Q) * inv_det;
-    u = dot3(T, M) * inv_det;
-    w = dot3(D, Q) * inv_det;
-    if (det > -0.0000001f && det < 0.0000001f)
-        return false;
-    if (dist < r0 || dist > r1)
-        return false;
-    if (u < 0.0f || u > 1.0f)
-        return false;
-    if (w < 0.0f || u + w > 1.0f)
-        return false;
-    return true;
-}
-
-// The search of a dealt stage: `parked` = the lanes in LT_LEAF (K of them, K <= SHRAY_DEAL_MAX_PARKED).  Returns true if
-// a worker accepted an unordered candidate (the caller then runs the plain loop); else the parked lane's winner in
-// (won, wd, wu, ww), won = 0xffffffff for none.  `ids`: 64 bytes of LDS owned by this wave (rank of a parked lane -> its
-// lane number)
-// CACHED: the stage's first kCacheSlots distinct leaves come through the wave's leaf cache (`ids` is followed by it); the
-// workers of a ray whose leaf got no slot fetch their triangles themselves, as before.
-// ROOMY: the instance is compiled for six waves per SIMD (80 registers): its rounds run as one hand-scheduled statement
-// (leaf_asm.h: dealt_rounds_scheduled).  Measured (profiles/EXPERIMENTS.md R6.3): a lone frame 0.356 -> 0.349 ms there, but the
-// seven- and eight-wave instances lose 2 % with it (throughput form 11,951 -> 11,743 Mrays/s, config 4 2.18 -> 2.21 ms): they keep
-// the compiler's rounds.
-template <bool COUNT, bool BOUNDS, bool CACHED, bool ROOMY = false>
-__device__ __forceinline__ bool dealt_search(const SceneView &sc, const LaneTraversal &t, int state, RayCounters &rc, uint8_t *ids,
-                                             unsigned long long parked, int K, float &wd, float &wu, float &ww,
-                                             uint32_t &won SHRAY_DIAG_PARAM)
-{
-    constexpr uint32_t kNoSlot = 0xffffffffu;
-    char *cache = reinterpret_cast<char *>(ids) + kIdsBytes;
-    uint32_t my_slot = kNoSlot;
-    const bool cached = CACHED && t.leaf_cap <= kCacheTriangles;   // (uniform; a larger leaf cap: every group fetches for itself)
-    if (cached) {
-        bool todo = state == LT_LEAF, now;
-        uint32_t at;
-        leaf_cache_fill(sc, t, todo, now, at, cache);
-        my_slot = now ? at : kNoSlot;
-    }
-    const int log_g = K <= 4 ? 4 : (K <= 8 ? 3 : (K <= 16 ? 2 : 1));   // G = 16, 8, 4, 2
-    const int G = 1 << log_g;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
-    if (state == LT_LEAF)
-        ids[rank] = (uint8_t)lane;
-    const int group = lane >> log_g, sub = lane & (G - 1);
-    const bool worker = group < K;
-    const int src = worker ? (int)ids[group] : lane;    // same wave, LDS operations complete in order
-    // the timed instances run their rounds as one hand-scheduled statement (leaf_asm.h: dealt_rounds_scheduled), which also
-    // pulls the ray -- behind the first round's fetches, so that the pulls' LDS round trips and the fetch overlap
-#if SHRAY_ASM_LEAF && !defined(SHRAY_DIAGNOSTICS)
-    constexpr bool SCHEDULED = ROOMY && !COUNT && BOUNDS && !CACHED;
-#else
-    constexpr bool SCHEDULED = false;
-#endif
-    // the parked ray, as its workers see it
-    V3 P = mk(0, 0, 0), D = mk(0, 0, 0);
-    float r0 = 0.0f, r1 = 0.0f;
-    if (!SCHEDULED) {
-        P = mk(lane_pull(src, t.P.x), lane_pull(src, t.P.y), lane_pull(src, t.P.z));
-        D = mk(lane_pull(src, t.D.x), lane_pull(src, t.D.y), lane_pull(src, t.D.z));
-        r0 = lane_pull(src, t.leaf_r0);
-        r1 = lane_pull(src, t.leaf_r1);
-    }
-    // worker i of a group walks triangles i, i + G, ... < count of its ray's leaf; the winner is kept as that number
-    const uint32_t first = (uint32_t)lane_pull(src, (int)t.leaf_first);
-    // (every pull is a statement of its own, executed by all 64 lanes: ds_bpermute returns 0 for a source lane that
-    // is masked off, so a pull must never sit inside a conditional expression)
-    const uint32_t count = parked_count((uint32_t)lane_pull(src, (int)t.leaf_count), t.leaf_cap);
-    uint32_t end = worker ? count : 0u;
-    asm volatile("" : "+v"(end));   // one comparison per round (see leaf_stage)
-    // where the worker's next triangle is: a byte offset into packed_tris -- or, if the ray's leaf has a slot in the cache,
-    // into the wave's slab (`served`)
-    uint32_t where = __umul24(first, 36u) + __umul24((uint32_t)sub, 36u);
-    bool served = false;
-    if (CACHED) {
-        const uint32_t slot = (uint32_t)lane_pull(src, (int)my_slot);
-        served = slot != kNoSlot;
-        if (served)
-            where = slot + __umul24((uint32_t)sub, 36u);
-        if (cached)
-            leaf_cache_wait(where);
-    }
-    float best_d = 0.0f, best_u = 0.0f, best_w = 0.0f;
-    if (!SCHEDULED)
-        best_d = lane_pull(src, t.hit.t);
-    uint32_t best = 0xffffffffu;    // no candidate accepted
-    uint32_t unordered_flag = 0u;   // accepted a candidate whose d is NaN (see above); set by the tied form below
-    SHRAY_DIAG_COUNT(6);
-    if (SCHEDULED) {
-        if (dealt_rounds_scheduled(sc, t, src << 2, end, (uint32_t)G, (uint32_t)sub, where, best_d, best_u, best_w, best)) {
-            asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");
-            return true;
-        }
-    } else {
-    // bottom-tested, like leaf_stage's loop: group 0's first worker always has a triangle
-    uint32_t tri = (uint32_t)sub;
-    do {
-        SHRAY_DIAG_COUNT(1);
-        if (tri < end) {
-            float4 q0, q1, q2;
-            if (CACHED && served)
-                load_cached_triangle(cache + where, q0, q1, q2);
-            else
-                load_packed_triangle_at(sc, where, q0, q1, q2);
-            if (COUNT)
-                rc.triangle_tests++;
-            float d, u, w;
-            if (triangle_candidate(P, D, r0, r1, q0, q1, q2, d, u, w) && !(d > best_d)) {
-                // the worker's best candidate so far is rewritten HERE only, deep inside the test's early-outs: as plain
-                // assignments the four values (and the flag, a lane mask) are copied back and forth at every level of that
-                // nest, ~24 moves and a dozen scalar mask operations per triangle; tied to their registers, none
-                asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\t"
-                             "v_cmp_u_f32 vcc, %5, %5\n\tv_cndmask_b32 %4, %4, 1, vcc"
-                             : "+v"(best_d), "+v"(best_u), "+v"(best_w), "+v"(best), "+v"(unordered_flag)
-                             : "v"(d), "v"(u), "v"(w), "v"(tri)
-                             : "vcc");
-                if (BOUNDS) {
-                    // r0, r1 are bounds of the leaf's range (lane_visit_loaded): a candidate within 2^-19 of an end is for the
-                    // exact range to decide -- the stage then runs the sequential loop, which does that (same flag)
-                    float scaled;
-                    asm volatile("v_mul_f32 %1, %4, %2\n\tv_cmp_lt_f32 vcc, %1, %3\n\tv_cndmask_b32 %0, %0, 1, vcc"
-                                 : "+v"(unordered_flag), "=&v"(scaled) : "v"(d), "v"(r0), "s"(kCheckDown) : "vcc");
-                    asm volatile("v_mul_f32 %1, %4, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_cndmask_b32 %0, %0, 1, vcc"
-                                 : "+v"(unordered_flag), "=&v"(scaled) : "v"(d), "v"(r1), "s"(kCheckUp) : "vcc");
-                }
-            }
-        }
-        tri += (uint32_t)G;
-        where += (uint32_t)G * 36u;
-    } while (wave_ballot(tri < end));
-    if (__builtin_expect(wave_ballot(unordered_flag != 0u) != 0ull, 0)) {
-        asm volatile("; unordered candidate: sequential leaf loop" ::: "memory");   // keeps this a branch
-        return true;    // the parked rays have not been touched yet; the triangle tests were tallied above
-    }
-    }
-    // combine inside each group: smaller d, of equal d the later triangle (no candidate = 0xffffffff loses)
-    for (int step = 1; step < G; step <<= 1) {
-        const int other = lane ^ step;
-        const float od = lane_pull(other, best_d);
-        const uint32_t ob = (uint32_t)lane_pull(other, (int)best);
-        const bool take = ob != 0xffffffffu && (best == 0xffffffffu || od < best_d || (od == best_d && ob > best));
-        const float ou = lane_pull(other, best_u), ow = lane_pull(other, best_w);
-        best_d = take ? od : best_d;
-        best_u = take ? ou : best_u;
-        best_w = take ? ow : best_w;
-        best = take ? ob : best;
-    }
-    // the parked lane collects its group's winner and moves on (fs:416-433)
-    const int from = rank << log_g;
-    wd = lane_pull(from, best_d);
-    wu = lane_pull(from, best_u);
-    ww = lane_pull(from, best_w);
-    won = (uint32_t)lane_pull(from, (int)best);
-    return false;
-}
-
-// One call site of the plain loop serves both the crowded stage (more than SHRAY_DEAL_MAX_PARKED lanes parked) and the
-// unordered fallback in the timed instances, and one end (leaf_finish) serves every path: each inlined copy is another
-// 150 instructions and another set of register copies where its results meet the other paths'.
-// CACHE: `ids` is followed by the wave's leaf cache; the crowded stage's sequential loop reads its triangles from there
-template <bool COUNT, int BLOCK, bool PAIR = false, bool CACHE = false, bool ROOMY = false>
-__device__ __forceinline__ void leaf_stage_dealt(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state,
-                                                 uint32_t *stack, RayCounters &rc, uint8_t *ids SHRAY_DIAG_PARAM)
-{
-    constexpr bool BOUNDS = !PAIR;   // the parked leaf range is a pair of bounds (lane_visit_loaded)
-    const unsigned long long parked = wave_ballot(state == LT_LEAF);
-    if (!parked)
-        return;
-    const int K = __popcll(parked);
-#if defined(SHRAY_DIAGNOSTICS) && defined(SHRAY_DIAG_KHIST)
-    {
-        unsigned int most = (state == LT_LEAF) ? parked_count(t.leaf_count, t.leaf_cap) : 0u;
-        for (int off = 32; off > 0; off >>= 1)
-            most = max(most, (unsigned int)__shfl_xor((int)most, off, 64));
-        const int bin = K == 1 ? 0 : (K == 2 ? 1 : (K <= 4 ? 2 : (K <= 8 ? 3 : (K <= 16 ? 4 : (K <= 32 ? 5 : 6)))));
-        const unsigned int g = K <= 4 ? 16u : (K <= 8 ? 8u : (K <= 16 ? 4u : (K <= 32 ? 2u : 1u)));
-        const unsigned long long rounds = (most + g - 1u) / g, chunks = (most * 9u + 3u) / 4u, staged = K > 32 ? 0ull : (chunks + g - 1u) / g;
-#if SHRAY_DIAG_KHIST == 1
-        diag_tally_ref[bin] += 1ull | (rounds << 24) | (staged << 44);
-        diag_tally_ref[7] += (unsigned long long)most | ((unsigned long long)K << 32);   // sums of the longest leaf and of K
-#else
-        // SHRAY_DIAG_KHIST == 2: the stages with more than SHRAY_DIAG_KHIST_FROM parked lanes by the number of DISTINCT leaves
-        // among them -- bins D = 1, 2, 3, 4, 5-8, 9-16, > 16 --, each word {stages; rounds}; [7] = sums of D and of K
-        if (K > SHRAY_DIAG_KHIST_FROM) {
-            unsigned long long left = parked;
-            int distinct = 0;
-            while (left) {
-                const int lead = __builtin_ctzll(left);
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)t.leaf_first, lead);
-                left &= ~wave_ballot(state == LT_LEAF && t.leaf_first == f);
-                distinct++;
-            }
-            const int dbin = distinct <= 4 ? distinct - 1 : (distinct <= 8 ? 4 : (distinct <= 16 ? 5 : 6));
-            diag_tally_ref[dbin] += 1ull | (rounds << 24);
-            diag_tally_ref[7] += (unsigned long long)distinct | ((unsigned long long)K << 32);
-        }
-        (void)bin;
-        (void)staged;
-#endif
-    }
-#endif
-    float wd = 0.0f, wu = 0.0f, ww = 0.0f;
-    uint32_t won = 0xffffffffu;
-    bool plain = K > SHRAY_DEAL_MAX_PARKED, tallied = false;
-    if (!plain) {
-        plain = dealt_search<COUNT, BOUNDS, CACHE && SHRAY_LEAF_CACHE_DEALT != 0, ROOMY>(sc, t, state, rc, ids, parked, K, wd, wu, ww, won SHRAY_DIAG_ARG_FWD);
-        tallied = true;
-    }
-    if (plain) {
-        if (CACHE && t.leaf_cap <= kCacheTriangles) {     // (uniform)
-            char *cache = reinterpret_cast<char *>(ids) + kIdsBytes;
-            if (COUNT && !tallied)
-                leaf_loop_cached<COUNT, BOUNDS>(sc, t, state, rc, cache SHRAY_DIAG_ARG_FWD);
-            else
-                leaf_loop_cached<false, BOUNDS>(sc, t, state, rc, cache SHRAY_DIAG_ARG_FWD);
-        } else if (COUNT && !tallied)
-            leaf_loop<COUNT, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
-        else
-            leaf_loop_timed_or_counted<false, BOUNDS>(sc, t, state, rc SHRAY_DIAG_ARG_FWD);
-    } else if (state == LT_LEAF && won != 0xffffffffu) {
-        // the parked lane takes its group's winner (its number in the leaf)
-        t.hit.which = (float)(t.leaf_first + won);
-        t.hit.t = wd;
-        t.hit.bu = wu;
-        t.hit.bv = ww;
-    }
-    leaf_finish<COUNT, BLOCK, PAIR>(sc, t, state, stack, rc);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Pair traversal: both children of a node in one turn.
-//
-// The reference visits a branch, then its near child, and its far child when everything under the near child is
-// done (fs:395-433): two visits, two dependent fetches.  Here the record of an entered branch holds BOTH children's
-// boxes (PackedPair, packed_layout.h): one fetch, two slab tests -- the near child's visit is decided at once, the
-// far child's visit is prepared and made when the reference makes it: when its word comes off the ray's stack.
-// What the far child's visit decides then is `!(r0 >= r1) && r0 < hit.t` (fs:400) with the hit distance of THAT
-// moment; r0 and r1 do not depend on the moment, so the word carries the first clause as a marker and r0 truncated
-// to the bits the node index leaves free (lower bound L <= r0 < U, its neighbour): `hit.t <= L` fails and
-// `U <= hit.t` passes with certainty; in between, and for every leaf (whose triangle tests need the exact clipped
-// range, fs:327-331), the child's own record is fetched and tested exactly as the reference does (LT_RETEST, served
-// at the start of the next leaf stage).  Every visit is counted where the reference makes it -- the near child's in
-// its parent's turn, a far child's when it is popped, whether it then passes, fails or was known to fail -- so the
-// iteration cap (fs:426-438) and the work counters come out exactly as in the one-visit-per-turn form.
-#ifndef SHRAY_PAIR_TURNS
-#define SHRAY_PAIR_TURNS 2
-#endif
-
-// the stack word of a pending child: (index | axis << IB | leaf << (IB + 2)) | r0's top 29 - IB bits << (IB + 3)
-__device__ __forceinline__ uint32_t pair_stack_word(uint32_t link, float r0, bool range_not_empty, uint32_t ib)
-{
-    const uint32_t s = ib + 3u;
-    const uint32_t low = (link & ((1u << ib) - 1u)) | ((link >> kPairAxisShift) << ib);
-    const uint32_t q = range_not_empty ? ((__float_as_uint(r0) & 0x7fffffffu) >> (s - 1u)) : (0xffffffffu >> s);
-    return low | (q << s);
-}
-
-// The visit is over: take the next pending child off the stack -- or several, while they fail.  Returns the lane's
-// next state: LT_WALK (t.node = a branch that is entered), LT_RETEST (t.node = a child whose own record decides),
-// LT_ENDED (the stack is empty, or the iteration cap struck: hit.t = -1).
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ int lane_pop(const SceneView &sc, LaneTraversal &t, uint32_t *stack, RayCounters &rc)
-{
-    const uint32_t ib = sc.pair_index_bits, s = ib + 3u;
-    for (;;) {
-        if (t.top == stack)
-            return LT_ENDED;           // finished: the cap does not apply to a finished ray
-        t.top -= BLOCK;
-        const uint32_t word = *t.top;
-        if (--t.left == 0) {           // fs:426-438: the visit that was about to be made is one too many
-            t.hit.t = -1.0f;
-            return LT_ENDED;
-        }
-        const uint32_t link = (word & ((1u << ib) - 1u)) | (((word >> ib) & 7u) << kPairAxisShift);
-        if (COUNT) {
-            rc.node_visits++;
-            if (link & kLeafFlag)
-                rc.leaf_visits++;
-        }
-        const uint32_t q = word >> s;
-        if (q == (0xffffffffu >> s))
-            continue;                  // its box range was empty: the visit fails whatever hit.t is
-        const float lower = __uint_as_float(q << (s - 1u)), upper = __uint_as_float((q + 1u) << (s - 1u));
-        if (t.hit.t <= lower)
-            continue;                  // r0 >= lower >= hit.t
-        t.node = link;
-        return (!(link & kLeafFlag) && upper <= t.hit.t) ? LT_WALK : LT_RETEST;   // r0 < upper <= hit.t: entered
-    }
-}
-
-// One turn of a lane in LT_WALK: t.node is a branch that has been entered; its near child is visited now.
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ int lane_pair_turn(const SceneView &sc, LaneTraversal &t, uint32_t *stack, RayCounters &rc)
-{
-    const uint32_t node = t.node;
-    const bool neg_first = (t.positive_dir >> ((node >> kPairAxisShift) & 3u)) & 1u;
-    // the near child's half of the record first (32-byte halves: negative child, positive child)
-    const uint32_t near_at = ((node & kPairIndexMask) << 6) + (neg_first ? 0u : 32u);
-    const char *base = reinterpret_cast<const char *>(sc.pair_nodes);
-    const float4 *np = reinterpret_cast<const float4 *>(base + near_at), *fp = reinterpret_cast<const float4 *>(base + (near_at ^ 32u));
-    const float4 nlo = np[0], nhi = np[1], flo = fp[0], fhi = fp[1];
-    if (--t.left == 0) {               // the near child's visit would be one too many (fs:426-438)
-        t.hit.t = -1.0f;
-        return LT_ENDED;
-    }
-    const uint32_t near_link = __float_as_uint(nlo.w), far_link = __float_as_uint(flo.w);
-    if (COUNT) {
-        rc.node_visits++;
-        if (near_link & kLeafFlag)
-            rc.leaf_visits++;
-    }
-    float n0, n1, f0, f1;
-    slab_range<false>(t, nlo, nhi, n0, n1);
-    slab_range<false>(t, flo, fhi, f0, f1);
-    *t.top = pair_stack_word(far_link, f0, !(f0 >= f1), sc.pair_index_bits);
-    t.top += BLOCK;
-    if (!(n0 >= n1) && (n0 < t.hit.t)) {
-        if (near_link & kLeafFlag) {
-            const uint32_t count = min((near_link >> kPairCountShift) & kPairCountMask, t.leaf_cap);
-            if (count > 0) {
-                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                             : "+v"(t.leaf_first), "+v"(t.leaf_count), "+v"(t.leaf_r0), "+v"(t.leaf_r1)
-                             : "v"(__float_as_uint(nhi.w)), "v"(count), "v"(n0), "v"(n1));
-                return LT_LEAF;
-            }
-        } else {
-            t.node = near_link;
-            return LT_WALK;
-        }
-    }
-    return lane_pop<COUNT, BLOCK>(sc, t, stack, rc);
-}
-
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ void inner_stage_pair(const SceneView &sc, LaneTraversal &t, int &state, uint32_t *stack,
-                                                 RayCounters &rc, int keep_walking)
-{
-    for (;;) {
-        if (!wave_ballot(state == LT_WALK))
-            return;
-#pragma unroll
-        for (int turn = 0; turn < SHRAY_PAIR_TURNS; turn++)
-            if (state == LT_WALK)
-                state = lane_pair_turn<COUNT, BLOCK>(sc, t, stack, rc);
-        const int walking = __popcll(wave_ballot(state == LT_WALK));
-        if (walking < keep_walking && wave_ballot((state & 1) == 0))
-            return;
-    }
-}
-
-// Start of a leaf stage: the lanes in LT_RETEST fetch their node's own record and make its visit's test exactly.
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ void retest_stage(const SceneView &sc, LaneTraversal &t, int &state, uint32_t *stack, RayCounters &rc)
-{
-    if (!wave_ballot(state == LT_RETEST))
-        return;
-    if (state == LT_RETEST) {
-        float4 lo, hi;
-        // (the node's own record, from the copy that holds the scene's boxes as they are: the last one)
-        load_packed_node(sc, ((t.node & kPairIndexMask) << kNodeShift) + 7u * sc.packed_nodes_bytes, lo, hi);
-        float r0, r1;
-        slab_range<false>(t, lo, hi, r0, r1);
-        const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-        state = LT_ENDED;              // placeholder: decided below
-        bool entered = false;
-        if (!(r0 >= r1) && (r0 < t.hit.t)) {
-            if (b & kLeafFlag) {
-                const uint32_t count = min(b & ~kLeafFlag, t.leaf_cap);
-                if (count > 0) {
-                    t.leaf_first = a;
-                    t.leaf_count = count;
-                    t.leaf_r0 = r0;
-                    t.leaf_r1 = r1;
-                    state = LT_LEAF;
-                    entered = true;
-                }
-            } else {
-                state = LT_WALK;       // t.node already carries the branch's index and split axis
-                entered = true;
-            }
-        }
-        if (!entered)
-            state = lane_pop<COUNT, BLOCK>(sc, t, stack, rc);
-    }
-}
-
 }   // namespace shray
 
-#include "leaf_asm.h"
+#include "leaf_stage.h"

@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t parked_count(uint32_t leaf_count, uint32_t l
 template <bool COUNT, bool BOUNDS>
 __device__ __forceinline__ void leaf_loop(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc SHRAY_DIAG_PARAM)
 {
-#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST) && !defined(SHRAY_DIAG_UNIFORM)
 #include "variants/diag_leaf_loop.inc"
 #endif
     // a lane that is not parked has no triangles: ONE comparison per round decides both who works and whether anyone does

@@ -101,7 +101,7 @@ struct StackTraversal {
     __device__ __forceinline__ void run(const SceneView &sc, const FrameView &fr, LaneTraversal &t, int &state, RayCounters &rc)
     {
         do {
-#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST) && !defined(SHRAY_DIAG_UNIFORM)
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
             // the threshold scales with the lanes still in this traversal: kStackKeepWalking of 64
@@ -120,7 +120,7 @@ struct StackTraversal {
 #endif
                     inner_stage<COUNT, BLOCK>(sc, fr, t, state, stack, rc, keep, false SHRAY_DIAG_ARG);
             }
-#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST) && !defined(SHRAY_DIAG_UNIFORM)
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
             if (DEAL && CONVERGED)
@@ -129,7 +129,7 @@ struct StackTraversal {
                 leaf_stage<COUNT, BLOCK, PAIR, CACHE>(sc, fr, t, state, stack, rc, ids SHRAY_DIAG_ARG);
             if (ANY_HIT && state != LT_ENDED && t.hit.t < kFar)
                 state = LT_ENDED;   // a hit: the shadow query is answered (a capped ray, t = -1, has ended already)
-#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST)
+#if defined(SHRAY_DIAGNOSTICS) && !defined(SHRAY_DIAG_KHIST) && !defined(SHRAY_DIAG_UNIFORM)
             const unsigned long long c2 = __builtin_amdgcn_s_memtime();
             diag_tally[2] += c1 - c0;
             diag_tally[3] += c2 - c1;

@@ -421,6 +421,9 @@ __device__ __forceinline__ void inner_stage(const SceneView &sc, const FrameView
                     float4 lo, hi;
                     load_packed_node_shared(sc, node_address(t, t.node), lo, hi);
                     SHRAY_DIAG_WAIT(4);
+#if defined(SHRAY_DIAGNOSTICS) && defined(SHRAY_DIAG_UNIFORM)
+#include "variants/diag_uniform_visit.inc"
+#endif
                     state = lane_visit_loaded<COUNT, BLOCK>(fr, t, stack, rc, lo, hi);
                 }
             }

@@ -42,47 +42,13 @@ namespace shray {
 #ifndef SHRAY_VISIT_SCALAR
 #define SHRAY_VISIT_SCALAR 1
 #endif
-#if SHRAY_VISIT_SCALAR
-#define SHRAY_VISIT_HEAD(K)                                                                                                      \
-    "s_waitcnt lgkmcnt(0)\n\t"                              /* the node the last turn took off the stack */                       \
-    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"              /* node_address(): (name << 3) + octant */                            \
-    "v_add_u32_e32 %[L], -1, %[L]\n\t"                      /* lane_count_visit (and the wait state in front of readfirstlane) */ \
-    "v_readfirstlane_b32 %[sF], %[A]\n\t"                                                                                       \
-    "s_nop 1\n\t"                                           /* a VALU-written SGPR read by a VALU: two wait states */             \
-    "v_cmp_ne_u32_e32 vcc, %[sF], %[A]\n\t"                                                                                     \
-    "s_cbranch_vccnz vv" #K "_%=\n\t"
-#else
-#define SHRAY_VISIT_HEAD(K)                                                                                                      \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
-    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"                                                                                  \
-    "v_add_u32_e32 %[L], -1, %[L]\n\t"                                                                                          \
-    "s_branch vv" #K "_%=\n\t"
+// (-DSHRAY_VISIT_RUNS=0, an A/B build: no uniform runs -- every turn finds out again whether its lanes are at one record, R6.8)
+#ifndef SHRAY_VISIT_RUNS
+#define SHRAY_VISIT_RUNS 1
 #endif
-#define SHRAY_VISIT_TURN(K)                                                                                                      \
-    SHRAY_VISIT_HEAD(K)                                                                                                          \
-    "s_load_dwordx8 s[64:71], %[base], %[sF]\n\t"           /* every lane at one record: once, through the scalar cache */       \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
-    "v_sub_f32_e32 v2, s64, %[Px]\n\t"                                                                                          \
-    "v_sub_f32_e32 v3, s65, %[Py]\n\t"                                                                                          \
-    "v_sub_f32_e32 v4, s66, %[Px]\n\t"                                                                                          \
-    "v_sub_f32_e32 v5, s67, %[Py]\n\t"                                                                                          \
-    "v_sub_f32_e32 v6, s68, %[Pz]\n\t"                                                                                          \
-    "v_sub_f32_e32 v7, s69, %[Pz]\n\t"                                                                                          \
-    "v_mov_b32_e32 v8, s70\n\t"                                                                                                 \
-    "v_mov_b32_e32 v9, s71\n\t"                                                                                                 \
-    "s_branch vj" #K "_%=\n"                                                                                                    \
-    "vv" #K "_%=:\n\t"                                                                                                          \
-    "global_load_dwordx4 v[2:5], %[A], %[base]\n\t"                                                                             \
-    "global_load_dwordx4 v[6:9], %[A], %[base] offset:16\n\t"                                                                   \
-    "s_waitcnt vmcnt(1)\n\t"                                                                                                    \
-    "v_sub_f32_e32 v2, v2, %[Px]\n\t"                                                                                           \
-    "v_sub_f32_e32 v3, v3, %[Py]\n\t"                                                                                           \
-    "v_sub_f32_e32 v4, v4, %[Px]\n\t"                                                                                           \
-    "v_sub_f32_e32 v5, v5, %[Py]\n\t"                                                                                           \
-    "s_waitcnt vmcnt(0)\n\t"                                                                                                    \
-    "v_sub_f32_e32 v6, v6, %[Pz]\n\t"                                                                                           \
-    "v_sub_f32_e32 v7, v7, %[Pz]\n"                                                                                             \
-    "vj" #K "_%=:\n\t"                                                                                                          \
+
+// the six products, the decision (see the file's header), and the way out for a turn the statement does not make
+#define SHRAY_VISIT_DECIDE                                                                                                       \
     "v_mul_f32_e32 v2, v2, %[Yx]\n\t"                                                                                           \
     "v_mul_f32_e32 v3, v3, %[Yy]\n\t"                                                                                           \
     "v_mul_f32_e32 v6, v6, %[Yz]\n\t"                                                                                           \
@@ -99,7 +65,98 @@ namespace shray {
     "s_or_b64 %[sT], %[sE], vcc\n\t"                                                                                            \
     "s_andn2_b64 %[sT], %[sT], %[sDIV]\n\t"                 /* decided, and not a lane that divides */                            \
     "s_andn2_b64 %[sT], exec, %[sT]\n\t"                                                                                        \
-    "s_cbranch_scc1 vslow_%=\n\t"                           /* some lane is not: the compiler's visit makes this turn */         \
+    "s_cbranch_scc1 vslow_%=\n\t"                           /* some lane is not: the compiler's visit makes this turn */
+
+// A turn whose walking lanes are all at ONE record (60 % of the headline's wave-visits; of those 56 % end with every lane entering,
+// profiles/r06/uniform_wave_visits_by_outcome.txt).  The record comes through the scalar cache and its planes are the subtractions'
+// scalar operands.  UNIFORM RUNS (round 6, R6.8): if the record is a branch's and EVERY walking lane enters it, every lane goes to
+// the same child and the next turn's lanes are at one record again -- its address is ((child's name) << 3) + the run's octant
+// offset, two scalar instructions -- so the next turn skips finding out (v_lshl_add, v_readfirstlane, v_cmp: three second-class
+// vector instructions and a two-state nop), and this turn's tail is the push alone: no leaf test, no pop, no lane masks.
+#if SHRAY_VISIT_SCALAR && SHRAY_VISIT_RUNS
+#define SHRAY_VISIT_HEAD(K)                                                                                                      \
+    "s_cmp_lg_u32 %[sKU], 0\n\t"                            /* inside a uniform run: the record's address is in sF already */     \
+    "s_cbranch_scc1 vk" #K "_%=\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                              /* the node the last turn took off the stack */                       \
+    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"              /* node_address(): (name << 3) + octant */                            \
+    "v_add_u32_e32 %[L], -1, %[L]\n\t"                      /* lane_count_visit (and the wait state in front of readfirstlane) */ \
+    "v_readfirstlane_b32 %[sF], %[A]\n\t"                                                                                       \
+    "s_nop 1\n\t"                                           /* a VALU-written SGPR read by a VALU: two wait states */             \
+    "v_cmp_ne_u32_e32 vcc, %[sF], %[A]\n\t"                                                                                     \
+    "s_cbranch_vccnz vv" #K "_%=\n\t"                                                                                           \
+    "v_readfirstlane_b32 %[sOCT], %[OCT]\n\t"               /* one record: one octant copy -- its offset, should a run begin */  \
+    "s_branch vu" #K "_%=\n"                                                                                                    \
+    "vk" #K "_%=:\n\t"                                                                                                          \
+    "v_add_u32_e32 %[L], -1, %[L]\n"                                                                                            \
+    "vu" #K "_%=:\n\t"
+#define SHRAY_VISIT_UNIFORM_TAIL(K)                                                                                              \
+    "s_mov_b32 %[sKU], 0\n\t"                                                                                                   \
+    SHRAY_VISIT_DECIDE                                                                                                           \
+    "s_cmp_eq_u64 %[sE], exec\n\t"                          /* every walking lane enters ... */                                   \
+    "s_cbranch_scc0 vm" #K "_%=\n\t"                                                                                            \
+    "s_bitcmp1_b32 s71, 31\n\t"                             /* ... a branch's record (b without the leaf flag) */                 \
+    "s_cbranch_scc1 vm" #K "_%=\n\t"                                                                                            \
+    "v_mov_b32_e32 v9, s71\n\t"                             /* the run goes on: push the other child, go to the first */          \
+    "ds_write_b32 %[T], v9\n\t"                                                                                                 \
+    "v_add_u32_e32 %[T], %[up], %[T]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[N], s70\n\t"                                                                                               \
+    "s_lshl_b32 %[sF], s70, 3\n\t"                          /* (the shift drops the axis bits of the child's name) */             \
+    "s_add_u32 %[sF], %[sF], %[sOCT]\n\t"                                                                                       \
+    "s_mov_b32 %[sKU], 1\n\t"                                                                                                   \
+    "s_branch ve" #K "_%=\n"                                                                                                    \
+    "vm" #K "_%=:\n\t"                                                                                                          \
+    "v_mov_b32_e32 v8, s70\n\t"                                                                                                 \
+    "v_mov_b32_e32 v9, s71\n\t"                                                                                                 \
+    "s_branch vt" #K "_%=\n"
+#elif SHRAY_VISIT_SCALAR
+#define SHRAY_VISIT_HEAD(K)                                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                              /* the node the last turn took off the stack */                       \
+    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"              /* node_address(): (name << 3) + octant */                            \
+    "v_add_u32_e32 %[L], -1, %[L]\n\t"                      /* lane_count_visit (and the wait state in front of readfirstlane) */ \
+    "v_readfirstlane_b32 %[sF], %[A]\n\t"                                                                                       \
+    "s_nop 1\n\t"                                           /* a VALU-written SGPR read by a VALU: two wait states */             \
+    "v_cmp_ne_u32_e32 vcc, %[sF], %[A]\n\t"                                                                                     \
+    "s_cbranch_vccnz vv" #K "_%=\n\t"
+#define SHRAY_VISIT_UNIFORM_TAIL(K)                                                                                              \
+    "v_mov_b32_e32 v8, s70\n\t"                                                                                                 \
+    "v_mov_b32_e32 v9, s71\n\t"                                                                                                 \
+    "s_branch vj" #K "_%=\n"
+#else
+#define SHRAY_VISIT_HEAD(K)                                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
+    "v_lshl_add_u32 %[A], %[N], 3, %[OCT]\n\t"                                                                                  \
+    "v_add_u32_e32 %[L], -1, %[L]\n\t"                                                                                          \
+    "s_branch vv" #K "_%=\n\t"
+#define SHRAY_VISIT_UNIFORM_TAIL(K)                                                                                              \
+    "v_mov_b32_e32 v8, s70\n\t"                                                                                                 \
+    "v_mov_b32_e32 v9, s71\n\t"                                                                                                 \
+    "s_branch vj" #K "_%=\n"
+#endif
+#define SHRAY_VISIT_TURN(K)                                                                                                      \
+    SHRAY_VISIT_HEAD(K)                                                                                                          \
+    "s_load_dwordx8 s[64:71], %[base], %[sF]\n\t"           /* every lane at one record: once, through the scalar cache */       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                  \
+    "v_sub_f32_e32 v2, s64, %[Px]\n\t"                                                                                          \
+    "v_sub_f32_e32 v3, s65, %[Py]\n\t"                                                                                          \
+    "v_sub_f32_e32 v4, s66, %[Px]\n\t"                                                                                          \
+    "v_sub_f32_e32 v5, s67, %[Py]\n\t"                                                                                          \
+    "v_sub_f32_e32 v6, s68, %[Pz]\n\t"                                                                                          \
+    "v_sub_f32_e32 v7, s69, %[Pz]\n\t"                                                                                          \
+    SHRAY_VISIT_UNIFORM_TAIL(K)                                                                                                  \
+    "vv" #K "_%=:\n\t"                                                                                                          \
+    "global_load_dwordx4 v[2:5], %[A], %[base]\n\t"                                                                             \
+    "global_load_dwordx4 v[6:9], %[A], %[base] offset:16\n\t"                                                                   \
+    "s_waitcnt vmcnt(1)\n\t"                                                                                                    \
+    "v_sub_f32_e32 v2, v2, %[Px]\n\t"                                                                                           \
+    "v_sub_f32_e32 v3, v3, %[Py]\n\t"                                                                                           \
+    "v_sub_f32_e32 v4, v4, %[Px]\n\t"                                                                                           \
+    "v_sub_f32_e32 v5, v5, %[Py]\n\t"                                                                                           \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                                    \
+    "v_sub_f32_e32 v6, v6, %[Pz]\n\t"                                                                                           \
+    "v_sub_f32_e32 v7, v7, %[Pz]\n"                                                                                             \
+    "vj" #K "_%=:\n\t"                                                                                                          \
+    SHRAY_VISIT_DECIDE                                                                                                           \
+    "\nvt" #K "_%=:\n\t"                                                                                                        \
     "v_cmp_gt_i32_e32 vcc, 0, v9\n\t"                       /* b's flag: a leaf's record */                                       \
     "s_and_b64 %[sL], %[sE], vcc\n\t"                       /* lanes that enter a leaf */                                         \
     "s_cbranch_scc0 vb" #K "_%=\n\t"                                                                                            \
@@ -127,7 +184,8 @@ namespace shray {
     "v_add_u32_e32 %[T], %[up], %[T]\n\t"                                                                                       \
     "v_mov_b32_e32 %[N], v8\n\t"                                                                                                \
     "s_mov_b64 exec, %[sW]\n\t"                                                                                                 \
-    "s_cbranch_execz vg_%=\n\t"
+    "s_cbranch_execz vg_%=\n"                                                                                                   \
+    "ve" #K "_%=:\n\t"
 
 // what the statement reports: the stage is over; a turn for the compiler's visit (`left` already counted); a lane is past the cap
 enum : uint32_t { VISIT_STAGE_OVER = 0, VISIT_SLOW_TURN = 1, VISIT_CAP = 2 };
@@ -171,13 +229,14 @@ __device__ __forceinline__ void inner_stage_scheduled(const SceneView &sc, const
     }
     lds_word *top = (lds_word *)t.top, *const base = (lds_word *)stack;
     for (;;) {
-        uint32_t reason, first, address;
+        uint32_t reason, first, address, in_a_run, run_octant;
         unsigned long long walking, parked, walked_in, entered, mask, leaves, saved;
         asm volatile(
             "s_mov_b64 %[saved], exec\n\t"
             "v_cmp_eq_u32_e64 %[sW], 1, %[ST]\n\t"             // LT_WALK
             "v_cmp_eq_u32_e64 %[sP], 2, %[ST]\n\t"             // LT_LEAF (parked by a turn the compiler's visit made)
             "s_mov_b64 %[sW0], %[sW]\n\t"
+            "s_mov_b32 %[sKU], 0\n\t"                           // no uniform run yet
             "s_cmp_eq_u64 %[sW], 0\n\t"
             "s_cbranch_scc1 vdone_%=\n"
             "vloop_%=:\n\t"
@@ -189,8 +248,8 @@ __device__ __forceinline__ void inner_stage_scheduled(const SceneView &sc, const
             "s_cbranch_vccnz vcap_%=\n\t"
             "s_cmp_eq_u64 %[sW], 0\n\t"
             "s_cbranch_scc1 vdone_%=\n\t"
-            "s_bcnt1_i32_b64 %[sF], %[sW]\n\t"
-            "s_cmp_ge_u32 %[sF], %[keep]\n\t"
+            "s_bcnt1_i32_b64 %[reason], %[sW]\n\t"          // (sF may hold a uniform run's next address: not a scratch register)
+            "s_cmp_ge_u32 %[reason], %[keep]\n\t"
             "s_cbranch_scc1 vloop_%=\n\t"
             "s_cmp_eq_u64 %[sP], 0\n\t"
             "s_cbranch_scc1 vloop_%=\n"
@@ -212,7 +271,7 @@ __device__ __forceinline__ void inner_stage_scheduled(const SceneView &sc, const
             : [N] "+v"(t.node), [T] "+v"(top), [L] "+v"(t.left), [ST] "+v"(state), [LF] "+v"(t.leaf_first), [LC] "+v"(t.leaf_count),
               [LR0] "+v"(t.leaf_r0), [LR1] "+v"(t.leaf_r1), [A] "=&v"(address), [sW] "=&s"(walking), [sP] "=&s"(parked),
               [sW0] "=&s"(walked_in), [sE] "=&s"(entered), [sT] "=&s"(mask), [sL] "=&s"(leaves), [saved] "=&s"(saved),
-              [sF] "=&s"(first), [reason] "=&s"(reason)
+              [sF] "=&s"(first), [reason] "=&s"(reason), [sKU] "=&s"(in_a_run), [sOCT] "=&s"(run_octant)
             : [Px] "v"(t.P.x), [Py] "v"(t.P.y), [Pz] "v"(t.P.z), [Yx] "v"(t.Y.x), [Yy] "v"(t.Y.y), [Yz] "v"(t.Y.z), [OCT] "v"(t.octant),
               [HT] "v"(t.hit.t), [B] "v"(base), [base] "s"(sc.packed_nodes), [sDIV] "s"(t.divide_mask), [keep] "s"(keep_walking),
               [up] "i"((unsigned int)(4 * BLOCK)), [down] "i"((unsigned int)(-4 * BLOCK))

@@ -37,11 +37,12 @@ def main():
     stamps = np.zeros((patches * 4, 16), dtype=np.uint64)
     N.check(lib.shray_debug_timeline(scene._handle, C.byref(params), W, H, 1, stamps.ctypes.data_as(C.c_void_p)))
     t = stamps[:, 4:12].astype(np.float64).sum(axis=0)
-    visits, uniform, all_enter, all_miss, mixed, lanes_uniform, uniform_leaf, lanes = t
+    visits, uniform, all_enter, all_miss, mixed, two, three_four, lanes = t
     print(f"scene: {'1M triangles' if args.million else 'bunny-class'}, material {args.material}, {W}x{H}, one frame (the start-up view)")
     print(f"wave-visits of the node stage          {visits:14.0f}   ({lanes / visits:.1f} walking lanes on average)")
-    print(f"  wave-uniform (one record)            {uniform:14.0f}   {uniform / visits:6.3f} of all   ({lanes_uniform / max(uniform, 1):.1f} lanes on average; "
-          f"{uniform_leaf / max(uniform, 1):.3f} of them at a leaf's record)")
+    print(f"  distinct records among the walking lanes: 1: {uniform / visits:.3f}   2: {two / visits:.3f}   3-4: {three_four / visits:.3f}   "
+          f"more: {(visits - uniform - two - three_four) / visits:.3f}")
+    print(f"  wave-uniform (one record)            {uniform:14.0f}   {uniform / visits:6.3f} of all")
     print(f"    every lane enters                  {all_enter:14.0f}   {all_enter / max(uniform, 1):6.3f} of the uniform ones")
     print(f"    no lane enters                     {all_miss:14.0f}   {all_miss / max(uniform, 1):6.3f}")
     print(f"    mixed                              {mixed:14.0f}   {mixed / max(uniform, 1):6.3f}")

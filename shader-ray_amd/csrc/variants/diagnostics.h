@@ -11,8 +11,8 @@
 // each word {stages, bits 0-23; rounds of three strided fetches the stage runs, bits 24-43; 16-byte-per-lane fetches a
 // stage would run if every group fetched its leaf's bytes as consecutive chunks, bits 44-63}; nothing is timed.
 // SHRAY_DIAG_UNIFORM (with SHRAY_DIAGNOSTICS; profiles/uniform_visit_histogram.py, round 6): the eight tallies count the node stage's
-// wave-visits -- {all, wave-uniform (every walking lane at one record), of those: every lane enters, no lane enters, mixed; walking
-// lanes in uniform visits; uniform visits of a leaf's record; walking lanes in all visits} (variants/diag_uniform_visit.inc).
+// wave-visits -- {all, wave-uniform (every walking lane at one record), of those: every lane enters, no lane enters, mixed; visits
+// with two distinct records, with three or four; walking lanes in all visits} (variants/diag_uniform_visit.inc).
 #if defined(SHRAY_DIAGNOSTICS) && (defined(SHRAY_DIAG_KHIST) || defined(SHRAY_DIAG_UNIFORM))
 #ifndef SHRAY_DIAG_KHIST_FROM
 #define SHRAY_DIAG_KHIST_FROM 32

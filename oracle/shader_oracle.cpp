@@ -283,6 +283,9 @@ struct Ctx {
     // relative to d; and the distance of Schlick's pow(x, 5.0) base from zero (negative: NaN, a black pixel)
     bool track_decisions = false;
     float decision_margin = 1.0f;
+    // (the quantised-record probe is on: read once per pixel, not from the global in every node visit -- ADVICE round 5: the
+    // diagnostics must not weigh on the loops bench.py's cpu_baseline times)
+    bool probe_quantised = false;
 };
 
 // optional per-pixel cost map: node visits summed over the pixel's samples (diagnostics)
@@ -515,7 +518,7 @@ void group_intersect(Ctx &cx, float root, const ray &theray, range prevr, surfac
         group gg = get_group(cx, g, offset);
         range r = range_intersect_box(gg.boxmin, gg.boxmax, theray, prevr);
         const uint64_t tests_before = cx.c.triangle_tests;
-        if (__builtin_expect(g_quant_step > 0.0f, 0))
+        if (__builtin_expect(cx.probe_quantised, 0))
             note_quantised_visit(gg.boxmin, gg.boxmax, theray.P, theray.D, prevr, hit.t);
         if ((!range_is_empty(r)) && (r.t0 < hit.t)) {
             if (!gg.is_branch) {
@@ -772,6 +775,7 @@ vec3 trace(Ctx &cx, ray worldray)
     cx.edge_margin = 1.0f;
     cx.decision_margin = 1.0f;
     cx.track_decisions = g_decision_map != nullptr;
+    cx.probe_quantised = g_quant_step > 0.0f;
     for (int i = 0; i < cx.p->bounce_count; i++) {
         ray reflected{};
         vec3 object_diffuse{}, object_specular{}, normal{};

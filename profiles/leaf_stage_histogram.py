@@ -3,7 +3,7 @@
     make -C shader-ray_amd variant VARIANT=khist HIP_EXTRA="-DSHRAY_DIAGNOSTICS -DSHRAY_DIAG_KHIST=1"
     SHRAY_DIAG_LIB=shader-ray_amd/_variants/libshray_hip_khist.so python profiles/leaf_stage_histogram.py [--million] [--material 6]
 Per bin of K: stages, rounds of three strided fetches they run today, 16-byte-per-lane fetches they would run if each
-group fetched its leaf as consecutive chunks (wave_traversal.h, SHRAY_DIAG_KHIST)."""
+group fetched its leaf as consecutive chunks (leaf_stage.h, variants/diag_khist_stage.inc, SHRAY_DIAG_KHIST)."""
 import argparse
 import ctypes as C
 import os

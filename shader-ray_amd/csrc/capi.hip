@@ -535,7 +535,7 @@ bool leaf_stage_policy(const shray_scene *scene, int frames_in_launch, int spp)
 // ring of slots (pinned staging -> device, on `stream`), then one launch renders them all.
 // tally / policy_frames: shray_render_counters_timed -- the instance a launch of `policy_frames` frames would run, with
 // per-ray work tallies
-// Which launches of the stack kernel test both children of a node per turn (wave_traversal.h: inner_stage_pair): those
+// Which launches of the stack kernel test both children of a node per turn (variants/pair_traversal.h: inner_stage_pair): those
 // of a scene that asked for it, shray_scene_set_kernel(scene, 3).  The pair form issues the same arithmetic and the same
 // loads as the one-visit form but about 0.6 of its dependent round trips, for a fatter turn; measured 24-35 % slower on
 // every configuration (profiles/EXPERIMENTS.md R3.2), so no launch chooses it by itself.
@@ -923,7 +923,7 @@ int shray_scene_create(const shray_scene_desc *desc, shray_scene **out_scene)
         uint32_t packed_root = 0;
         tb.pack(nodes, &packed_root);
         const size_t nt = nv / 3;
-        std::vector<PackedTri> tris(nt + 1);   // a spare record: the leaf cache fetches a leaf in 16-byte chunks (wave_traversal.h)
+        std::vector<PackedTri> tris(nt + 1);   // a spare record: the leaf cache fetches a leaf in 16-byte chunks (leaf_cache.h)
         for (size_t t = 0; t < nt; t++) {
             const float *v = desc->vertex_positions + 9 * t;
             PackedTri &pt = tris[t];

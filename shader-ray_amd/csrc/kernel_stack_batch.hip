@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(kBatchBlock, min_waves(METAL, DEAL, ONE_SAMPLE
 
 // Several spp == 1 zero-diffuse frames per launch (the throughput form): the dealt leaf stage at SEVEN waves per SIMD
 // (72 registers, 28 B of scratch outside the loops).  Round 2 gave these launches the plain leaf loop for its eighth wave;
-// since the dealt loop lost its register copies (round 3, wave_traversal.h) seven dealing waves beat eight plain ones by
+// since the dealt loop lost its register copies (round 3, leaf_stage.h) seven dealing waves beat eight plain ones by
 // 2.7 %, while a lone frame still does best with six (no scratch): profiles/history/r03/dealt_occupancy_ab2.txt.
 __global__ void __launch_bounds__(kBatchBlock, SHRAY_MIN_WAVES_DEALT_DENSE)
     trace_stack_batch_dense_kernel(SceneView sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride, int stack_levels,

@@ -77,7 +77,7 @@ inline bool plain_view(const FrameView &fr) { return !(fr.which == 1 || fr.which
 #ifndef SHRAY_LDS_PAD
 #define SHRAY_LDS_PAD 0u   // unused LDS per wave (occupancy experiments)
 #endif
-// the batch instances whose sequential leaf loop reads its triangles from the wave's leaf cache in LDS (wave_traversal.h)
+// the batch instances whose sequential leaf loop reads its triangles from the wave's leaf cache in LDS (leaf_cache.h)
 constexpr bool caches_leaves(bool pair) { return SHRAY_LEAF_CACHE != 0 && !pair; }
 
 // The multi-sample instances with the plain leaf loop (cache-resident scenes: configs 3 and 5) keep the words of the sample loop
@@ -109,10 +109,10 @@ __device__ __forceinline__ StackTraversal<BLOCK, DEAL, PAIR, CACHE, ROOMY> make_
 
 // The body of every convergent batch kernel: one-wave workgroups, four (times the lanes per pixel of a multi-sample
 // frame) per 16x16 patch.
-// DEAL: the dealt leaf stage (wave_traversal.h) instead of the plain leaf loop.
+// DEAL: the dealt leaf stage (leaf_stage.h) instead of the plain leaf loop.
 // TALLY: 0 = the timed kernels; 1 = the same form with per-ray work tallies (what the timed form does); 2 = tallies of
 // the reference's walk (one lane per pixel, every shadow ray to its end) -- the counting twin of the pair traversal.
-// PAIR: both children of a node per turn (wave_traversal.h).  ORDERED: the launch reads a dispatch order (capi.hip).
+// PAIR: both children of a node per turn (variants/pair_traversal.h).  ORDERED: the launch reads a dispatch order (capi.hip).
 // ROOMY: the kernel is compiled for six waves per SIMD (stack_traversal.h).
 template <bool ONE_SAMPLE, bool METAL, bool DEAL, int TALLY, bool PAIR, bool ORDERED = false, bool ROOMY = false>
 __device__ __forceinline__ void stack_batch_body(const SceneView &sc, const FrameView *__restrict__ frames, float4 *out, size_t frame_stride,

@@ -1,7 +1,7 @@
 // kernel_stack_tally.hip -- kernel id 0: the batch instances with per-ray work tallies (shray_render_counters_timed: what
 // the TIMED form does -- sample lanes, shadow rays that stop at their first hit -- as opposed to the counting twins of
 // kernel_stack.hip, which reproduce the reference's full traversals; never timed), and kernel id 3, the pair traversal
-// (both children of a node per turn, wave_traversal.h: inner_stage_pair), timed and tallying.
+// (both children of a node per turn, variants/pair_traversal.h: inner_stage_pair), timed and tallying.
 #include "kernel_stack_common.h"
 #include "variants/pair_traversal.h"   // the pair instances (kernel id 3) live in this translation unit only
 

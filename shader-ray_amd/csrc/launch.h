@@ -22,14 +22,14 @@ hipError_t launch_stack(const SceneView &sc, const FrameView &fr, float4 *out, D
 // out + k * frame_stride (in float4 units); `first` is frame 0's view (grid shape, differential class)
 // all_metal: every frame's diffuse colour is zero (selects the kernel instance without the diffuse branch)
 // all_plain: every frame is a plain which == 0 frame (the convergent driver applies); deal: the instances that deal
-// leaf triangles to idle lanes (wave_traversal.h) instead of the plain leaf loop
+// leaf triangles to idle lanes (leaf_stage.h) instead of the plain leaf loop
 // tally: nullptr for the timed launches; else the same instance with per-ray work tallies added into `tally`
 // (kCounterShards copies) -- what the timed form does (shray_render_counters_timed)
 hipError_t launch_stack_batch(const SceneView &sc, const FrameView *d_frames, int count, const FrameView &first, bool all_metal,
                               bool all_plain, bool deal, float4 *out, size_t frame_stride, hipStream_t stream, int stack_levels,
                               DeviceCounters *tally = nullptr, bool pair = false, bool tally_full_walk = false, bool ordered = false);
 // ordered: the frames carry a dispatch order / cost buffer (capi.hip: DispatchOrder): the instances that read them
-// pair: the instances that test both children of a node per turn (wave_traversal.h: inner_stage_pair; the scene needs
+// pair: the instances that test both children of a node per turn (variants/pair_traversal.h: inner_stage_pair; the scene needs
 // pair_nodes); tally_full_walk: with `tally` and `pair`, the tallies of the reference's walk instead of the timed form's
 
 // kernel id 2 (kernel_pool.hip): the workgroup's rays as a pool whose waves merge during the traversal;

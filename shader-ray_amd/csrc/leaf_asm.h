@@ -1,12 +1,12 @@
 // leaf_asm.h -- the sequential leaf loop of the timed instances, hand-scheduled for gfx950 (round 6).
 //
-// wave_traversal.h: leaf_loop is the same loop as the compiler writes it: per round ~80 vector and ~32 scalar instructions -- five
+// leaf_stage.h: leaf_loop is the same loop as the compiler writes it: per round ~80 vector and ~32 scalar instructions -- five
 // nested early-outs of triangle_intersect (fs:312-340), each an exec save / and / branch / restore ladder around a block that, in
 // a wave with fifty testing lanes, is almost never skipped.  Here a round is straight-line code: every early-out is ONE v_cmpx
 // that takes the failing lanes out of EXEC (their later arithmetic is simply not executed for them; nothing is saved, EXEC is
 // set again from a scalar copy when the round is over), the loop's own test is one v_cmpx per round instead of two compares,
 // and the stores happen under whatever EXEC is left.  Same operations on the same operands in the same order as
-// triangle_distance / triangle_barycentrics (wave_traversal.h): bit-identical hits.  68 vector (+ 3 fetches) and 8 scalar
+// triangle_distance / triangle_barycentrics (leaf_stage.h): bit-identical hits.  68 vector (+ 3 fetches) and 8 scalar
 // instructions per round.
 // What is rare leaves the statement BEFORE anything is stored, and the round is made by the compiler's form (which holds the
 // true division and the exact leaf range): a determinant outside the three-instruction reciprocal's domain (>= 2^100, or NaN),
@@ -17,7 +17,7 @@
 
 namespace shray {
 
-// leaf_loop<false, true> (wave_traversal.h): every lane in LT_LEAF tests its leaf's triangles in order.  Some lane is parked.
+// leaf_loop<false, true> (leaf_stage.h): every lane in LT_LEAF tests its leaf's triangles in order.  Some lane is parked.
 // Registers of the statement: v[2:5] v[6:9] v10 the triangle { v0.xyz, e0.x } { e0.yz, e1.xy } { e1.z }; v11-v13 M = e1 x D;
 // v14, v15 products; v16 det, then the distance; v17 1 / det; v18-v20 T = P - v0; v2-v4 again: Q = T x e0; v14 u, v15 w.
 __device__ __forceinline__ void leaf_loop_scheduled(const SceneView &sc, LaneTraversal &t, int state, RayCounters &rc)
@@ -156,7 +156,7 @@ __device__ __forceinline__ void leaf_loop_scheduled(const SceneView &sc, LaneTra
     }
 }
 
-// The rounds of a dealt leaf stage (wave_traversal.h: dealt_search) the same way: worker lane `sub` of a group tests triangles
+// The rounds of a dealt leaf stage (leaf_stage.h: dealt_search) the same way: worker lane `sub` of a group tests triangles
 // sub, sub + G, ... < end of its ray's leaf -- the ray (P, D), its parked bounds (r0, r1) and the hit distance it starts from
 // (best_d) pulled from the parked lane -- and keeps, over its own increasing triangle numbers, the candidate the sequential loop
 // would keep: every early-out of triangle_candidate is one v_cmpx, then `!(d > best_d)`.  Returns true where dealt_search's flag

@@ -51,7 +51,7 @@ static_assert(sizeof(PackedNode) == 32, "PackedNode must be 32 bytes");
 
 // A record of an octant copy as it lies in device memory (round 5): the same eight words as PackedNode, ordered so that the two
 // 16-byte loads of a visit leave { entry.x, entry.y } { exit.x, exit.y } { entry.z, exit.z } in three aligned register pairs --
-// the operands of the visit's six packed fp32 instructions (wave_traversal.h: slab_range_fast), where PackedNode's order took
+// the operands of the visit's six packed fp32 instructions (variants/packed_slab.h: slab_range_fast), where PackedNode's order took
 // twelve plain ones.  load_packed_node hands the words back in PackedNode's order to everything else.
 struct DeviceNode {
     float entry_xy[2];
@@ -68,7 +68,7 @@ struct PackedTri {
 };
 static_assert(sizeof(PackedTri) == 36, "PackedTri must be 36 bytes");
 
-// Sibling pairs for the pair traversal (wave_traversal.h: inner_stage_pair): the record of inner node N holds the
+// Sibling pairs for the pair traversal (variants/pair_traversal.h: inner_stage_pair): the record of inner node N holds the
 // boxes of BOTH its children, so that one memory round trip serves two of the reference's visits.  64 B, indexed like
 // PackedNode (only inner nodes' records are read):
 //     { neg.boxmin, neg.link } { neg.boxmax, neg.info } { pos.boxmin, pos.link } { pos.boxmax, pos.info }

@@ -11,7 +11,7 @@
 //     correctly rounded reciprocal plus two FMA refinements that land on the same correctly
 //     rounded quotient (exact_div.h); rays or scenes outside the proven operand ranges keep
 //     dividing
-//   * node visits and triangle tests are stages of one wave-cooperative loop (wave_traversal.h: inner_stage,
+//   * node visits and triangle tests are stages of one wave-cooperative loop (wave_traversal.h: inner_stage; leaf_stage.h:
 //     leaf_stage / leaf_stage_dealt) so that one lane's leaf does not stall the other 63
 #pragma once
 
@@ -39,15 +39,15 @@ constexpr int kStackKeepWalkingDealt = SHRAY_KEEP_WALKING_DEALT;
 #ifndef SHRAY_KEEP_FLOOR
 #define SHRAY_KEEP_FLOOR 2
 #endif
-// DEAL: the convergent form's leaf stage deals triangles to idle lanes (wave_traversal.h: leaf_stage_dealt)
-// PAIR: both children of a node per turn (wave_traversal.h: inner_stage_pair); convergent form only
-// CACHE: the sequential leaf loop reads a stage's distinct leaves from the wave's LDS slab (wave_traversal.h: leaf cache; `ids` is followed by it)
-// ROOMY: an instance compiled for six waves per SIMD: the dealt stage's rounds are hand-scheduled too (wave_traversal.h: dealt_search)
+// DEAL: the convergent form's leaf stage deals triangles to idle lanes (leaf_stage.h: leaf_stage_dealt)
+// PAIR: both children of a node per turn (variants/pair_traversal.h: inner_stage_pair); convergent form only
+// CACHE: the sequential leaf loop reads a stage's distinct leaves from the wave's LDS slab (leaf_cache.h; `ids` is followed by it)
+// ROOMY: an instance compiled for six waves per SIMD: the dealt stage's rounds are hand-scheduled too (leaf_stage.h: dealt_search)
 template <int BLOCK, bool DEAL = true, bool PAIR = false, bool CACHE = false, bool ROOMY = false>
 struct StackTraversal {
     static constexpr int block_size = BLOCK;
     uint32_t *stack;   // LDS, this thread's column: stack[level * BLOCK]
-    uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (wave_traversal.h)
+    uint8_t *ids;      // LDS, 64 bytes per wave: scratch of the dealt leaf stage (leaf_stage.h)
 #ifdef SHRAY_DIAGNOSTICS
     unsigned long long diag_tally[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif

@@ -1,7 +1,7 @@
 // uniform_driver.h -- trace() of raytracer.es.fs:552-582 with CONVERGENT control flow: every thread of the
 // group that traverses together (a wave for the stack kernel, the workgroup for the pool kernel) runs every
 // bounce of every sample and enters each traversal with the others; `has_ray` says whether its pixel still
-// carries a ray.  The traversals need that: the stack kernel's dealt leaf stage (wave_traversal.h) uses the
+// carries a ray.  The traversals need that: the stack kernel's dealt leaf stage (leaf_stage.h) uses the
 // wave's idle lanes as workers, the pool kernel synchronises its four waves.  The per-lane statements are
 // those of trace_common.h: trace_ray (same arithmetic, same order); only which == 0 frames come here.
 //

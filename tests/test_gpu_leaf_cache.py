@@ -1,6 +1,6 @@
 """The library with the leaf cache compiled in (shader-ray_amd/libshray_hip_leafcache.so: a leaf stage's distinct leaves
 fetched once, as consecutive 16-byte chunks, straight into LDS and read from there -- north_star's "triangle data staged
-into LDS tiles with coalesced loads", csrc/wave_traversal.h).  It is not the shipped library (measured slower,
+into LDS tiles with coalesced loads", csrc/leaf_cache.h).  It is not the shipped library (measured slower,
 profiles/EXPERIMENTS.md R5.1); this test keeps it parity-green: the oracle-parity tests and the fuzz run once more against
 it, in ONE child process (SHRAY_HIP_LIB selects the library when the package is first imported)."""
 import os

@@ -12,11 +12,12 @@
 // are undefined behaviour upstream; here they fail the load.
 //
 // Unlike the reference this parser keeps faces in flat arrays and scans the
-// file in place; since round 4 in parallel: the text is cut at line ends into one piece per thread, each piece is scanned
-// into arrays of its own and the arrays are appended in file order (a face's indices are absolute, so nothing has to
-// be renumbered); the synthesized normals are summed per vertex in face order by the thread that owns the vertex (the
-// float sums are those of the serial loop), and the triangles go to triangle_set::add_bulk.  Same arrays, same
-// triangle_set, bit for bit (tests/test_loaders.py compares with SHRAY_LOAD_THREADS=1).
+// file in place (mapped read-only, round 6); since round 4 in parallel: the text is cut at line ends into one piece per
+// thread, each piece is scanned into arrays of its own and the arrays are copied, every piece by its own thread, one behind
+// the other in file order (a face's indices are absolute, so nothing has to be renumbered); the synthesized normals are
+// summed per vertex in face order by the thread that owns the vertex (the float sums are those of the serial loop), and the
+// triangles go to triangle_set::add_bulk.  Same arrays, same triangle_set, bit for bit (tests/test_loaders.py compares
+// with SHRAY_LOAD_THREADS=1; tests/test_host_vs_reference.py with the reference's own loader).
 #include "obj-support.h"
 
 #include "host-log.h"
@@ -25,6 +26,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
+#include <new>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -181,19 +189,30 @@ void Obj::synthesize_normals()
 
 bool Obj::indices_in_range(std::string *why) const
 {
-    for (size_t f = 0; f < face_first.size(); f++) {
-        if (face_size[f] < 3) {
-            *why = "a face has fewer than 3 corners";
+    const int threads = host_load_threads();
+    std::vector<char> found((size_t)threads, 0);     // 1: a short face, 2: a position that does not exist (the first in file order is reported)
+    std::vector<size_t> found_at((size_t)threads, 0);
+    host_in_parallel(threads, [&](int j) {
+        const size_t lo = face_first.size() * (size_t)j / threads, hi = face_first.size() * (size_t)(j + 1) / threads;
+        for (size_t f = lo; f < hi && !found[(size_t)j]; f++) {
+            if (face_size[f] < 3) {
+                found[(size_t)j] = 1;
+                found_at[(size_t)j] = f;
+                break;
+            }
+            for (unsigned int k = 0; k < face_size[f]; k++)
+                if (corners[face_first[f] + k].v >= positions.size()) {
+                    found[(size_t)j] = 2;
+                    found_at[(size_t)j] = f;
+                    break;
+                }
+        }
+    });
+    for (int j = 0; j < threads; j++)
+        if (found[(size_t)j]) {
+            *why = found[(size_t)j] == 1 ? "a face has fewer than 3 corners" : "a face names a position that does not exist";
             return false;
         }
-        for (unsigned int k = 0; k < face_size[f]; k++) {
-            const corner &c = corners[face_first[f] + k];
-            if (c.v >= positions.size()) {
-                *why = "a face names a position that does not exist";
-                return false;
-            }
-        }
-    }
     return true;
 }
 
@@ -239,20 +258,41 @@ void Obj::scan_lines(const char *text, const char *text_end)
     }
 }
 
-// the arrays of the next piece of the file, behind this one's
-void Obj::append(Obj &&chunk)
+// the arrays of the file's pieces one behind the other, in file order (a face's indices are absolute: nothing is renumbered)
+void Obj::append_all(std::vector<Obj> &piece)
 {
-    const size_t corner_offset = corners.size();
-    positions.insert(positions.end(), chunk.positions.begin(), chunk.positions.end());
-    normals.insert(normals.end(), chunk.normals.begin(), chunk.normals.end());
-    texcoords.insert(texcoords.end(), chunk.texcoords.begin(), chunk.texcoords.end());
-    corners.insert(corners.end(), chunk.corners.begin(), chunk.corners.end());
-    for (size_t first : chunk.face_first)
-        face_first.push_back(first + corner_offset);
-    face_size.insert(face_size.end(), chunk.face_size.begin(), chunk.face_size.end());
-    face_attribs.insert(face_attribs.end(), chunk.face_attribs.begin(), chunk.face_attribs.end());
-    for (std::string &name : chunk.object_names)
-        object_names.push_back(std::move(name));
+    const size_t n = piece.size();
+    std::vector<size_t> at_position(n + 1, positions.size()), at_normal(n + 1, normals.size()), at_texcoord(n + 1, texcoords.size()),
+        at_corner(n + 1, corners.size()), at_face(n + 1, face_first.size());
+    for (size_t j = 0; j < n; j++) {
+        at_position[j + 1] = at_position[j] + piece[j].positions.size();
+        at_normal[j + 1] = at_normal[j] + piece[j].normals.size();
+        at_texcoord[j + 1] = at_texcoord[j] + piece[j].texcoords.size();
+        at_corner[j + 1] = at_corner[j] + piece[j].corners.size();
+        at_face[j + 1] = at_face[j] + piece[j].face_first.size();
+    }
+    positions.resize(at_position[n]);
+    normals.resize(at_normal[n]);
+    texcoords.resize(at_texcoord[n]);
+    corners.resize(at_corner[n]);
+    face_first.resize(at_face[n]);
+    face_size.resize(at_face[n]);
+    face_attribs.resize(at_face[n]);
+    host_in_parallel((int)n, [&](int k) {
+        const size_t j = (size_t)k;
+        Obj &chunk = piece[j];
+        std::copy(chunk.positions.begin(), chunk.positions.end(), positions.begin() + (ptrdiff_t)at_position[j]);
+        std::copy(chunk.normals.begin(), chunk.normals.end(), normals.begin() + (ptrdiff_t)at_normal[j]);
+        std::copy(chunk.texcoords.begin(), chunk.texcoords.end(), texcoords.begin() + (ptrdiff_t)at_texcoord[j]);
+        std::copy(chunk.corners.begin(), chunk.corners.end(), corners.begin() + (ptrdiff_t)at_corner[j]);
+        for (size_t f = 0; f < chunk.face_first.size(); f++)
+            face_first[at_face[j] + f] = chunk.face_first[f] + at_corner[j];
+        std::copy(chunk.face_size.begin(), chunk.face_size.end(), face_size.begin() + (ptrdiff_t)at_face[j]);
+        std::copy(chunk.face_attribs.begin(), chunk.face_attribs.end(), face_attribs.begin() + (ptrdiff_t)at_face[j]);
+    });
+    for (Obj &chunk : piece)
+        for (std::string &name : chunk.object_names)
+            object_names.push_back(std::move(name));
 }
 
 bool Obj::load_object_from_text(const char *text, size_t length)
@@ -273,8 +313,7 @@ bool Obj::load_object_from_text(const char *text, size_t length)
     } else {
         std::vector<Obj> piece((size_t)threads);
         host_in_parallel(threads, [&](int j) { piece[(size_t)j].scan_lines(cut[(size_t)j], cut[(size_t)j + 1]); });
-        for (Obj &chunk : piece)
-            append(std::move(chunk));
+        append_all(piece);
     }
     for (const std::string &name : object_names)
         host_info("obj: object '%s'\n", name.c_str());
@@ -296,6 +335,21 @@ bool Obj::load_object_from_text(const char *text, size_t length)
 
 bool Obj::load_object_from_file(const std::string &filename)
 {
+    // the file mapped read-only and scanned where it lies; what cannot be mapped (a pipe, an empty file) is read
+    const int fd = open(filename.c_str(), O_RDONLY);
+    if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map != MAP_FAILED) {
+                close(fd);
+                const bool ok = load_object_from_text((const char *)map, (size_t)st.st_size);
+                munmap(map, (size_t)st.st_size);
+                return ok;
+            }
+        }
+        close(fd);
+    }
     FILE *fp = fopen(filename.c_str(), "rb");
     if (!fp)
         return false;
@@ -314,7 +368,11 @@ bool Obj::fill_triangle_set(triangle_set_ptr triangles)
     std::vector<size_t> triangle_first(face_first.size() + 1, 0);
     for (size_t f = 0; f < face_first.size(); f++)
         triangle_first[f + 1] = triangle_first[f] + (face_size[f] >= 3 ? face_size[f] - 2 : 0);
-    std::vector<vertex> tri_corners(3 * triangle_first.back());
+    // (raw storage: every corner is constructed by the thread that fills it in, not all of them here first)
+    struct raw_free {
+        void operator()(vertex *p) const { ::operator delete((void *)p); }
+    };
+    std::unique_ptr<vertex, raw_free> tri_corners((vertex *)::operator new(sizeof(vertex) * std::max<size_t>(1, 3 * triangle_first.back())));
     const int threads = host_load_threads();
     std::vector<char> missing_normal((size_t)threads, 0);
     host_in_parallel(threads, [&](int j) {
@@ -322,10 +380,11 @@ bool Obj::fill_triangle_set(triangle_set_ptr triangles)
         for (size_t f = lo; f < hi; f++) {
             const corner *fc = &corners[face_first[f]];
             const bool with_normals = (face_attribs[f] & HAS_NORMAL) != 0;
-            vertex *out = tri_corners.data() + 3 * triangle_first[f];
+            vertex *out = tri_corners.get() + 3 * triangle_first[f];
             for (unsigned int k = 1; k + 1 < face_size[f]; k++) {
                 const corner *pick[3] = {&fc[0], &fc[k], &fc[k + 1]};
                 for (int c = 0; c < 3; c++, out++) {
+                    new (out) vertex();
                     out->v = positions[pick[c]->v];
                     if (with_normals) {
                         if (pick[c]->vn >= normals.size()) {
@@ -344,6 +403,6 @@ bool Obj::fill_triangle_set(triangle_set_ptr triangles)
             fprintf(stderr, "obj: a face names a normal that does not exist\n");
             return false;
         }
-    triangles->add_bulk(tri_corners.data(), triangle_first.back(), threads);
+    triangles->add_bulk(tri_corners.get(), triangle_first.back(), threads);
     return true;
 }

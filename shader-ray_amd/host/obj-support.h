@@ -47,7 +47,7 @@ private:
     std::vector<std::string> object_names;      // the `o` lines, in file order
 
     void scan_lines(const char *begin, const char *end);
-    void append(Obj &&chunk);
+    void append_all(std::vector<Obj> &piece);
     void parse_attribute(const char *begin, const char *end, vec3 &out);
     void parse_face(const char *begin, const char *end);
     void synthesize_normals();

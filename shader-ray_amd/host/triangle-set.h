@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -45,15 +46,17 @@ struct triangle_set {
     // Appends `count` triangles at once -- corners[3 t + k] = corner k of triangle t -- with the result add() would give
     // called on them one after the other: the same vertex numbering (first seen first), the same triangles, the same box.
     // The loaders hand a whole file over in one call (round 4: the 1M-triangle OBJ spent 0.5 s of its 0.85 s in three
-    // million hash look-ups on one core).  How: every corner's key and hash in parallel; the keys are sharded by hash, and
-    // each shard's thread walks ALL corners in order interning its own -- so a shard's vertices come out in first-seen
-    // order with the corner that introduced each --; the shards' lists are merged by that corner number, which is the
-    // global first-seen order; the triangles are then written in parallel.  threads <= 0: hardware_concurrency().
+    // million hash look-ups on one core).  How (round 6: no copy of the keys, no node-based map, no sort): every corner's
+    // hash in parallel; the corner numbers are partitioned by hash into shards, in corner order; each shard's thread interns
+    // its own corners in an open-addressing table whose entries are corner numbers (two corners are one vertex when their
+    // nine canonical words agree) and notes for every corner the corner that introduced its vertex; a vertex's global number
+    // is the count of introducing corners in front of its own -- a prefix sum, which IS the first-seen order --; the
+    // triangles are then written in parallel.  threads <= 0: hardware_concurrency().
     void add_bulk(const vertex *corners, size_t count, int threads = 0)
     {
         if (count == 0)
             return;
-        if (!lookup.empty() || !vertices.empty() || count < 4096) {     // something is interned already: one by one
+        if (!lookup.empty() || !vertices.empty() || count < 4096 || count > 0x50000000u) {     // something is interned already: one by one
             for (size_t t = 0; t < count; t++)
                 add(corners[3 * t], corners[3 * t + 1], corners[3 * t + 2]);
             return;
@@ -67,62 +70,105 @@ struct triangle_set {
         const unsigned shards = 1u << shard_bits;
         auto in_parallel = [&](unsigned jobs, auto &&fn) {
             std::vector<std::thread> pool;
-            for (unsigned j = 1; j < jobs; j++)
-                pool.emplace_back([&fn, j] { fn(j); });
+            unsigned started = 1;
+            for (; started < jobs; started++) {
+                try {
+                    pool.emplace_back([&fn, started] { fn(started); });
+                } catch (const std::system_error &) {     // (a thread the system refuses: its job, and the rest, on this one)
+                    break;
+                }
+            }
             fn(0u);
+            for (unsigned j = started; j < jobs; j++)
+                fn(j);
             for (std::thread &th : pool)
                 th.join();
         };
-        // 1. keys and hashes
-        std::vector<key> keys(n);
-        std::vector<uint64_t> hashes(n);
+        // 1. hashes; how many corners of each worker's range fall into each shard
+        std::unique_ptr<uint64_t[]> hashes(new uint64_t[n]);
+        const uint64_t shard_mask = shards - 1u;
+        std::vector<uint32_t> tally((size_t)workers * shards, 0u);
         in_parallel(workers, [&](unsigned j) {
             const size_t lo = n * j / workers, hi = n * (j + 1) / workers;
+            uint32_t *mine = &tally[(size_t)j * shards];
             for (size_t c = lo; c < hi; c++) {
-                keys[c] = key_of(corners[c]);
-                hashes[c] = (uint64_t)key_hash()(keys[c]);
+                const uint64_t h = (uint64_t)key_hash()(key_of(corners[c]));
+                hashes[c] = h;
+                mine[(h >> 40) & shard_mask]++;
             }
         });
-        // 2. per shard: its corners in order
-        struct shard_result {
-            std::vector<uint32_t> first_corner;     // local vertex -> the corner that introduced it
-        };
-        std::vector<shard_result> result(shards);
-        std::vector<uint32_t> local_of(n);
-        const uint64_t shard_mask = shards - 1u;
-        in_parallel(shards, [&](unsigned s) {
-            std::unordered_map<key, uint32_t, key_hash> seen;
-            seen.reserve(n / shards / 2 + 16);
-            shard_result &r = result[s];
-            for (size_t c = 0; c < n; c++) {
-                if (((hashes[c] >> 40) & shard_mask) != s)
-                    continue;
-                auto found = seen.find(keys[c]);
-                if (found == seen.end()) {
-                    found = seen.emplace(keys[c], (uint32_t)r.first_corner.size()).first;
-                    r.first_corner.push_back((uint32_t)c);
+        // 2. the corner numbers by shard, in corner order inside a shard (worker ranges are in corner order)
+        std::vector<size_t> shard_begin(shards + 1, 0);
+        std::vector<size_t> cursor((size_t)workers * shards);
+        {
+            size_t run = 0;
+            for (unsigned s = 0; s < shards; s++) {
+                shard_begin[s] = run;
+                for (unsigned j = 0; j < workers; j++) {
+                    cursor[(size_t)j * shards + s] = run;
+                    run += tally[(size_t)j * shards + s];
                 }
-                local_of[c] = found->second;
+            }
+            shard_begin[shards] = run;
+        }
+        std::unique_ptr<uint32_t[]> listed(new uint32_t[n]);
+        in_parallel(workers, [&](unsigned j) {
+            const size_t lo = n * j / workers, hi = n * (j + 1) / workers;
+            size_t *at = &cursor[(size_t)j * shards];
+            for (size_t c = lo; c < hi; c++)
+                listed[at[(hashes[c] >> 40) & shard_mask]++] = (uint32_t)c;
+        });
+        // 3. per shard: intern its corners in order; introduced_by[c] = the corner that brought c's vertex in (c itself: a new vertex)
+        std::unique_ptr<uint32_t[]> introduced_by(new uint32_t[n]);
+        in_parallel(shards, [&](unsigned s) {
+            const size_t lo = shard_begin[s], hi = shard_begin[s + 1];
+            size_t capacity = 16;
+            while (capacity < 2 * (hi - lo))
+                capacity <<= 1;
+            const uint32_t empty = 0xffffffffu;
+            std::vector<uint32_t> table(capacity, empty);
+            for (size_t k = lo; k < hi; k++) {
+                const uint32_t c = listed[k];
+                const key mine = key_of(corners[c]);
+                size_t slot = (size_t)hashes[c] & (capacity - 1);
+                for (;;) {
+                    const uint32_t other = table[slot];
+                    if (other == empty) {
+                        table[slot] = c;
+                        introduced_by[c] = c;
+                        break;
+                    }
+                    if (key_of(corners[other]) == mine) {
+                        introduced_by[c] = other;
+                        break;
+                    }
+                    slot = (slot + 1) & (capacity - 1);
+                }
             }
         });
-        // 3. the global numbering: by the corner that introduced the vertex
-        struct entry {
-            uint32_t first_corner, shard, local;
-        };
-        std::vector<entry> order;
-        for (unsigned s = 0; s < shards; s++)
-            for (size_t k = 0; k < result[s].first_corner.size(); k++)
-                order.push_back(entry{result[s].first_corner[k], s, (uint32_t)k});
-        std::sort(order.begin(), order.end(), [](const entry &a, const entry &b) { return a.first_corner < b.first_corner; });
-        std::vector<std::vector<uint32_t>> global_of(shards);
-        for (unsigned s = 0; s < shards; s++)
-            global_of[s].resize(result[s].first_corner.size());
-        vertices.resize(order.size());
-        for (size_t g = 0; g < order.size(); g++) {
-            global_of[order[g].shard][order[g].local] = (uint32_t)g;
-            vertices[g] = corners[order[g].first_corner];
-        }
-        // 4. the triangles
+        // 4. the global numbering: a new vertex's number = how many corners in front of its own introduced one
+        std::unique_ptr<uint32_t[]> number_at(new uint32_t[n]);
+        std::vector<size_t> introduced(workers + 1, 0);
+        in_parallel(workers, [&](unsigned j) {
+            const size_t lo = n * j / workers, hi = n * (j + 1) / workers;
+            size_t mine = 0;
+            for (size_t c = lo; c < hi; c++)
+                mine += introduced_by[c] == (uint32_t)c;
+            introduced[j + 1] = mine;
+        });
+        for (unsigned j = 0; j < workers; j++)
+            introduced[j + 1] += introduced[j];
+        vertices.resize(introduced[workers]);
+        in_parallel(workers, [&](unsigned j) {
+            const size_t lo = n * j / workers, hi = n * (j + 1) / workers;
+            size_t next = introduced[j];
+            for (size_t c = lo; c < hi; c++)
+                if (introduced_by[c] == (uint32_t)c) {
+                    number_at[c] = (uint32_t)next;
+                    vertices[next++] = corners[c];
+                }
+        });
+        // 5. the triangles
         triangles.reserve(count);
         triangles.resize(count, indexed_triangle(0, 0, 0, corners[0], corners[1], corners[2]));
         std::vector<box3d> boxes(workers);
@@ -130,10 +176,8 @@ struct triangle_set {
             const size_t lo = count * j / workers, hi = count * (j + 1) / workers;
             for (size_t t = lo; t < hi; t++) {
                 int index[3];
-                for (int k = 0; k < 3; k++) {
-                    const size_t c = 3 * t + k;
-                    index[k] = (int)global_of[(hashes[c] >> 40) & shard_mask][local_of[c]];
-                }
+                for (int k = 0; k < 3; k++)
+                    index[k] = (int)number_at[introduced_by[3 * t + k]];
                 triangles[t] = indexed_triangle(index[0], index[1], index[2], corners[3 * t], corners[3 * t + 1], corners[3 * t + 2]);
                 boxes[j].add(triangles[t].box);
             }

@@ -91,6 +91,15 @@ def main():
                       "--deselect", os.path.join(ROOT, "tests", "test_loaders.py") + "::test_threaded_loaders_equal_the_serial_loaders", *tests])
     if rc != 0:
         sys.exit(int(rc) or 1)
+    # whole files through triangle_set::add_bulk (4,096 triangles and more: hashed shards, open-addressing tables) and, for the
+    # OBJ, the mapped file and the pieces' parallel append -- the fuzz seeds below are too small to reach them
+    import helpers
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    for path in (helpers.bunny_trisrc(), helpers.million_obj()):
+        world = pkg.World(path)
+        assert world.info.triangle_count >= 4096, path
+        world.close()
     with tempfile.TemporaryDirectory() as tmp:
         tally = fuzz(cases, seed, tmp)
     print("SANITIZER_CHILD_OK", tally, flush=True)

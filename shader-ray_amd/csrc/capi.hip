@@ -496,7 +496,7 @@ unsigned long long dispatch_period()
 {
     static const unsigned long long period = [] {
         const char *e = getenv("SHRAY_DISPATCH_PERIOD");
-        const long long v = e ? atoll(e) : 8;
+        const long long v = e ? atoll(e) : 32;
         return (unsigned long long)(v < 1 ? 1 : v);
     }();
     return period;
@@ -510,8 +510,17 @@ bool dispatch_order_enabled()
     return on;
 }
 
-// a re-sort follows a shape's first three launches and every dispatch_period()-th from then on
-bool dispatch_sorts_after(unsigned long long launch_number) { return launch_number <= 3 || launch_number % dispatch_period() == 0; }
+// A re-sort follows a shape's first three launches, then launches 4, 8, 16 ... up to the period, and every dispatch_period()-th
+// from then on.  Round 6 (profiles/r06/dispatch_period_ab.txt): the costs between two re-sorts are the maximum over the launches
+// between them and halve at every re-sort, so eight launches between re-sorts made the order follow the last eight views -- on
+// an orbit of twenty that is the half the next frames are NOT in -- and cost a 10-40 us kernel per eight frames; thirty-two cover
+// the orbit (a lone frame of it 0.400 -> 0.387 ms), the doubling start keeps a new shape's first orders coming as fast as before.
+bool dispatch_sorts_after(unsigned long long launch_number)
+{
+    if (launch_number <= 3 || launch_number % dispatch_period() == 0)
+        return true;
+    return launch_number < dispatch_period() && (launch_number & (launch_number - 1)) == 0;
+}
 
 // costs below (16 - bulk) / 16 of a shape's largest keep their row-major order among themselves (tuning: SHRAY_DISPATCH_BULK)
 int dispatch_bulk_class()
